@@ -1,0 +1,179 @@
+/* sprk.h — C ABI of libsprk.so: the MI355X (gfx950) kernels behind spr_pick's joint
+ * denoise+detect hot path.
+ *
+ * The reference (nextpyp/spr_pick) has no FFI on this path: it calls stock torch.nn /
+ * NumPy from Python.  Each entry point below therefore replaces a *torch or NumPy call
+ * site* of the reference (cited per function as file:line under /root/reference) and
+ * is what a maintainer binds with ctypes from the reference's Python modules — see
+ * INTEGRATION.md for the stubs.
+ *
+ * Conventions
+ *   - all tensors are fp32, contiguous NCHW, DEVICE pointers (unless marked host);
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it and
+ *     re-entrant per stream; nothing is allocated or synchronised inside;
+ *   - the caller owns every buffer incl. the workspace `ws` (size from *_ws_bytes);
+ *   - return 0 on success, a negative SPRK_E* code otherwise; sprk_last_error() gives
+ *     a thread-local message.
+ */
+#ifndef SPRK_H
+#define SPRK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPRK_OK 0
+#define SPRK_EINVAL (-1)   /* bad argument / unsupported geometry */
+#define SPRK_EWORKSPACE (-2) /* workspace too small */
+#define SPRK_ELAUNCH (-3)  /* hip launch error */
+
+#define SPRK_ACT_NONE 0
+#define SPRK_ACT_LEAKY 1   /* LeakyReLU(0.1) */
+#define SPRK_ACT_RELU 2
+
+/* Geometry of one 2-D convolution  y[N,Cout,Hout,Wout] = conv(in[N,C1+C2,Hin,Win], w).
+ * The conv input is the channel concatenation of up to two sources:
+ *   src1: x  [N,C1,Hin,Win]           (up1 = 0)
+ *         x  [N,C1,Hin/2,Win/2]       (up1 = 1: nearest x2 upsampling fused into the load)
+ *   src2: x2 [N,C2,Hin,Win]           (C2 may be 0, x2 NULL)
+ * which is torch.cat((Upsample(2)(a), skip), 1) of the reference's U-Nets
+ * (models/joint_network_v2.py:212-227) without materialising it.
+ * Padding is asymmetric and explicit: rows/cols outside [0,Hin)x[0,Win) read as zero,
+ * Hout/Wout are given by the caller.  ShiftConv2d (joint_network_v2.py:565-584) is
+ * pad_top = 2*(KH/2), pad_left = KW/2, Hout = Hin, Wout = Win. */
+typedef struct sprk_conv_geom {
+    int32_t N, C1, C2, Hin, Win, up1;
+    int32_t Cout, Hout, Wout;
+    int32_t KH, KW, stride, dil, pad_top, pad_left;
+} sprk_conv_geom;
+
+/* Optional fused epilogue of sprk_conv2d_fwd, applied in this order:
+ *   v = acc (+ res[n,co,oy+res_off,ox+res_off])            res: [N,Cout,res_h,res_w]
+ *   v = scale ? v*scale[co] + shift[co] : v + (bias ? bias[co] : 0)
+ *   v = act(v)
+ * (residual add + eval-mode BatchNorm affine + ReLU of ResidA, feature_extractor.py:384-416). */
+typedef struct sprk_conv_epilogue {
+    const float *bias, *scale, *shift, *res;
+    int32_t res_h, res_w, res_off;
+    int32_t act;
+} sprk_conv_epilogue;
+
+const char *sprk_last_error(void);
+int sprk_version(void);
+/* number of HIP kernel launches issued by this library since load (diagnostics) */
+long sprk_launch_count(void);
+/* debug switch: 1 = route convolutions through the direct (non-MFMA) kernels */
+void sprk_set_naive(int on);
+
+/* ---- convolution: replaces F.conv2d/F.pad/crop of nn.Conv2d / ShiftConv2d ------------
+ * reference: models/joint_network_v2.py:565-584 (ShiftConv2d), :33-153 (all U-Net convs),
+ * models/joint_network_v2_shallow.py:33-150, models/feature_extractor.py:285,335-343,
+ * models/classifier.py:11.  w is the reference layout [Cout][C1+C2][KH][KW]. */
+size_t sprk_conv2d_fwd_ws_bytes(const sprk_conv_geom *g);
+int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y,
+                    const sprk_conv_geom *g, const sprk_conv_epilogue *ep,
+                    void *ws, size_t ws_bytes, void *stream);
+/* gin[N,C1+C2,Hin,Win] = d loss / d (concatenated conv input), given gy = d loss / d (pre-activation y) */
+size_t sprk_conv2d_bwd_data_ws_bytes(const sprk_conv_geom *g);
+int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk_conv_geom *g,
+                         void *ws, size_t ws_bytes, void *stream);
+/* gw[Cout][C1+C2][KH][KW] = d loss / d w  (overwritten, not accumulated) */
+size_t sprk_conv2d_bwd_weight_ws_bytes(const sprk_conv_geom *g);
+int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, float *gw,
+                           const sprk_conv_geom *g, void *ws, size_t ws_bytes, void *stream);
+/* gpre = gy * act'(y) where y is the saved POST-activation output (gpre may alias gy; with
+ * act == NONE nothing is written to gpre and it may be NULL); if gbias != NULL also
+ * gbias[c] = sum over n,h,w of gpre (conv bias gradient).  ws: C*nsplit floats. */
+size_t sprk_act_bwd_ws_bytes(int N, int C, int HW);
+int sprk_act_bwd(const float *gy, const float *y, float *gpre, float *gbias, int act,
+                 int N, int C, int HW, void *ws, size_t ws_bytes, void *stream);
+/* split the gradient of a fused (upsample2(a) ++ b) conv input: ga[N,C1,H/2,W/2] = 2x2 sums
+ * of gin[:, :C1], gb[N,C2,H,W] = gin[:, C1:].  (autograd of nn.Upsample + torch.cat) */
+int sprk_concat_up_bwd(const float *gin, float *ga, float *gb, int N, int C1, int C2, int H, int W,
+                       int up1, void *stream);
+
+/* ---- U-Net plumbing (HBM-bound) --------------------------------------------------------
+ * Shift2d((1,0)) + MaxPool2d(2): models/joint_network_v2.py:27-30, models/utility.py:46-72;
+ * shift = 0 gives the plain MaxPool2d(2) of the sigma net (joint_network_v2_shallow.py). */
+int sprk_shift_maxpool2_fwd(const float *x, float *y, int NC, int H, int W, int shift, void *stream);
+int sprk_shift_maxpool2_bwd(const float *gy, const float *x, float *gx, int NC, int H, int W, int shift, void *stream);
+/* rotate(x,{0,90,180,270}) + cat(dim=0): joint_network_v2.py:198-200, utils/data.py:43-68.
+ * x [B,C,P,P] -> y [4B,C,P,P]; bwd sums the four inverse rotations into gx. */
+int sprk_rot4_stack_fwd(const float *x, float *y, int B, int C, int P, void *stream);
+int sprk_rot4_stack_bwd(const float *gy, float *gx, int B, int C, int P, void *stream);
+/* Shift2d((1,0)) + chunk(4) + rotate({0,270,180,90}) + cat(dim=1): joint_network_v2.py:230-239.
+ * d [4B,C,P,P] -> f [B,4C,P,P] */
+int sprk_unrot4_shift_concat_fwd(const float *d, float *f, int B, int C, int P, void *stream);
+int sprk_unrot4_shift_concat_bwd(const float *gf, float *gd, int B, int C, int P, void *stream);
+
+/* ---- BatchNorm2d (+ optional ReLU), detector: joint_network_v2.py:547,558;
+ * feature_extractor.py:287-288,320-324,338-346,412-414.
+ * train: batch statistics (biased var for normalisation, unbiased for the running update,
+ * momentum 0.1) saved to save_mean/save_invstd [C]; eval: running statistics. */
+int sprk_bn_train_fwd(const float *x, float *y, const float *gamma, const float *beta,
+                      float *running_mean, float *running_var, float *save_mean, float *save_invstd,
+                      int N, int C, int HW, float momentum, float eps, int relu, void *stream);
+int sprk_bn_eval_fwd(const float *x, float *y, const float *gamma, const float *beta,
+                     const float *running_mean, const float *running_var,
+                     int N, int C, int HW, float eps, int relu, void *stream);
+/* gy is d loss / d y (post-ReLU if relu); y is the saved output (for the ReLU mask). */
+int sprk_bn_train_bwd(const float *gy, const float *x, const float *y, const float *gamma,
+                      const float *save_mean, const float *save_invstd,
+                      float *gx, float *ggamma, float *gbeta,
+                      int N, int C, int HW, int relu, void *stream);
+
+/* ---- per-pixel maths of the pipeline ---------------------------------------------------
+ * reparameterize: z = mu + eps * A^2 on out_stats [B,2,H,W] (joint_network_v2.py:469-475) */
+int sprk_reparam_fwd(const float *out_stats, const float *eps, float *z, int B, int HW, void *stream);
+/* g_out_stats [B,2,HW] (overwritten): d/dmu = gz, d/dA = gz * eps * 2A */
+int sprk_reparam_bwd(const float *gz, const float *out_stats, const float *eps, float *g_out_stats,
+                     int B, int HW, void *stream);
+/* _sigmoid: clamp(sigmoid(x), 1e-4, 1-1e-4)  (denoiser_v2.py:32-34) */
+int sprk_sigmoid_clamp_fwd(const float *x, float *p, long n, void *stream);
+int sprk_sigmoid_clamp_bwd(const float *gp, const float *x, float *gx, long n, void *stream);
+/* SSDN gaussian likelihood + posterior mean (denoiser_v2.py:449-462, :514):
+ *   var_x = A^2, var_n = s^2, var_y = var_x + var_n
+ *   nll = (x-mu)^2/var_y + log var_y - 0.05 s      -> loss[b] = mean over HW
+ *   pme = (x var_x + mu var_n)/var_y ;  model_std = sqrt(var_x)
+ * x [B,1,HW], out_stats [B,2,HW], noise_std [B]; pme/model_std [B,HW]; loss [B].
+ * ws: B*nblk floats of partial sums. */
+size_t sprk_ssdn_ws_bytes(int B, int HW);
+int sprk_ssdn_fwd(const float *x, const float *out_stats, const float *noise_std,
+                  float *loss, float *pme, float *model_std, int B, int HW,
+                  void *ws, size_t ws_bytes, void *stream);
+/* gloss [B] = d L / d loss[b];  g_out_stats [B,2,HW] (overwritten), g_noise_std [B] */
+int sprk_ssdn_bwd(const float *gloss, const float *x, const float *out_stats, const float *noise_std,
+                  float *g_out_stats, float *g_noise_std, int B, int HW,
+                  void *ws, size_t ws_bytes, void *stream);
+
+/* ---- 2-D greedy non-maximum suppression ------------------------------------------------
+ * replaces non_maximum_suppression(x, r, contam=set(), threshold) —
+ * utils/algorithms.py:59-103, call site train.py:564.  Exact greedy semantics incl. the
+ * reference's clip-to-H/W border behaviour; ties: score desc, then flat index desc.
+ * scores [H,W] device; out_scores[max_out], out_xy[max_out][2] (x=col, y=row) device,
+ * written in pick order (descending score).
+ * out_count: device int32[2]: [0] = number of picks found (if it exceeds max_out the
+ * stored list is incomplete: call again with a larger max_out), [1] = pixels still
+ * undecided after `rounds` relaxation launches.  The suppression fixed point is reached
+ * by repeated launches (no host sync inside): when [1] != 0 call again with resume = 1
+ * (state is kept in ws) until it is 0; typical score maps need < 10 rounds. */
+size_t sprk_nms2d_ws_bytes(int H, int W, int max_out);
+int sprk_nms2d(const float *scores, int H, int W, int r, float threshold,
+               float *out_scores, int32_t *out_xy, int32_t *out_count, int max_out,
+               int rounds, int resume, void *ws, size_t ws_bytes, void *stream);
+
+/* ---- in-library kernel timing (bench.py's roofline leg) --------------------------------
+ * When enabled, every launch of the MFMA convolution kernels is bracketed by HIP events
+ * on its own stream; sprk_prof_collect synchronises those events and returns, per kernel
+ * class (0 = conv fwd / bwd-data MFMA, 1 = conv bwd-weight MFMA), the launch count, the
+ * summed duration in ms and the summed algorithmic FLOPs. */
+void sprk_prof_enable(int on);
+int sprk_prof_collect(int kclass, long *launches, double *ms, double *flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPRK_H */

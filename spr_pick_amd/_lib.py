@@ -1,0 +1,91 @@
+"""ctypes binding of libsprk.so (include/sprk.h).  The product path has no fallback: if the
+library is missing or a call fails, this module raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsprk.so")
+
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+
+c_f = ctypes.c_void_p      # device float*
+c_i = ctypes.c_int
+c_vp = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+
+class ConvGeom(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("N", "C1", "C2", "Hin", "Win", "up1", "Cout", "Hout", "Wout",
+                 "KH", "KW", "stride", "dil", "pad_top", "pad_left")]
+
+
+class ConvEpilogue(ctypes.Structure):
+    _fields_ = [("bias", c_vp), ("scale", c_vp), ("shift", c_vp), ("res", c_vp),
+                ("res_h", ctypes.c_int32), ("res_w", ctypes.c_int32), ("res_off", ctypes.c_int32),
+                ("act", ctypes.c_int32)]
+
+
+_SIGS = {
+    "sprk_last_error": (ctypes.c_char_p, []),
+    "sprk_version": (c_i, []),
+    "sprk_launch_count": (ctypes.c_long, []),
+    "sprk_set_naive": (None, [c_i]),
+    "sprk_conv2d_fwd_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
+    "sprk_conv2d_fwd": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue), c_vp, c_sz, c_vp]),
+    "sprk_conv2d_bwd_data_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
+    "sprk_conv2d_bwd_data": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
+    "sprk_conv2d_bwd_weight_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
+    "sprk_conv2d_bwd_weight": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
+    "sprk_act_bwd_ws_bytes": (c_sz, [c_i, c_i, c_i]),
+    "sprk_act_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "sprk_concat_up_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "sprk_shift_maxpool2_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),
+    "sprk_shift_maxpool2_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),
+    "sprk_rot4_stack_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
+    "sprk_rot4_stack_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
+    "sprk_unrot4_shift_concat_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
+    "sprk_unrot4_shift_concat_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
+    "sprk_bn_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_i, c_vp]),
+    "sprk_bn_eval_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_vp]),
+    "sprk_bn_train_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),
+    "sprk_reparam_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_vp]),
+    "sprk_reparam_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_vp]),
+    "sprk_sigmoid_clamp_fwd": (c_i, [c_f, c_f, ctypes.c_long, c_vp]),
+    "sprk_sigmoid_clamp_bwd": (c_i, [c_f, c_f, c_f, ctypes.c_long, c_vp]),
+    "sprk_ssdn_ws_bytes": (c_sz, [c_i, c_i]),
+    "sprk_ssdn_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_vp, c_sz, c_vp]),
+    "sprk_ssdn_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_vp, c_sz, c_vp]),
+    "sprk_nms2d_ws_bytes": (c_sz, [c_i, c_i, c_i]),
+    "sprk_nms2d": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "sprk_prof_enable": (None, [c_i]),
+    "sprk_prof_collect": (c_i, [c_i, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib = None
+
+
+class SprkError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libsprk.so (once).  Raises if it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SprkError("libsprk.so not found at %s — build it with `make -C spr_pick_amd/csrc` "
+                            "or __graft_entry__.build(); spr_pick_amd has no fallback path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise SprkError("%s failed (%d): %s" % (what, rc, lib().sprk_last_error().decode()))

@@ -1,0 +1,63 @@
+// Internal helpers shared by the libsprk.so translation units (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/sprk.h"
+
+namespace sprk {
+
+void set_error(const char *fmt, ...);
+extern std::atomic<long> g_launches;
+extern int g_naive;
+
+// event bracketing of the MFMA convolution launches (sprk_prof_*)
+void prof_begin(int kclass, double flops, hipStream_t s);
+void prof_end(int kclass, hipStream_t s);
+
+inline int check_launch(const char *what) {
+    g_launches.fetch_add(1, std::memory_order_relaxed);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return SPRK_ELAUNCH;
+    }
+    return SPRK_OK;
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
+inline int pow2_ceil(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+inline int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+#define SPRK_REQUIRE(cond, ...)                \
+    do {                                       \
+        if (!(cond)) {                         \
+            sprk::set_error(__VA_ARGS__);      \
+            return SPRK_EINVAL;                \
+        }                                      \
+    } while (0)
+
+// grid-stride launch size for HBM-bound elementwise kernels (guide: cap ~2048 blocks)
+inline int ew_blocks(long n, int threads = 256) {
+    long b = (n + threads - 1) / threads;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace sprk
+
+// exact floor(a / d) for 0 <= a < 2^21 via a float reciprocal (inv = 1.0f / d)
+__device__ __forceinline__ int fast_div(int a, float inv) { return (int)(((float)a + 0.5f) * inv); }

@@ -1,0 +1,964 @@
+// Convolution kernels of libsprk.so (gfx950 / MI355X).
+//
+// All convolutions of the hot path are implicit GEMMs on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32, k-ordered fma chain) over NCHW tensors:
+//
+//   forward / backward-data :  Out[pixel][cout] += A[pixel][k] * Wt[k][cout],  k = (tap, cin)
+//        A-fragment lane l -> pixel l&15, k l>>4 : 16 consecutive pixels of a row, straight
+//        from an LDS copy of the input tile (with halo, zero-filled outside the image), so
+//        the im2col matrix is never formed;  B-fragment from an LDS copy of the
+//        pre-transposed weight rows.
+//   backward-weight         :  dW[k][cout] += X[k][pixel] * G[pixel][cout]  (pixels are the
+//        reduced dimension; per-block partials + a deterministic reduction pass).
+//
+// LDS plane strides are chosen per kernel so that the two k-values (fwd) / two pixels (bwd-w)
+// held by one 32-lane ds_read group fall on disjoint banks (MI355X_MICROARCH.md §LDS).
+// The "direct" kernels at the end are the plain per-output-element statement of the same
+// maths: they serve strided backward-data (tiny detector layers) and as an on-device
+// cross-check (sprk_set_naive).
+#include "common.h"
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr float kLeak = 0.1f;
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == SPRK_ACT_LEAKY) return v > 0.f ? v : v * kLeak;
+    if (act == SPRK_ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// weight transform:  W[Cout][Cin][KHW]  ->  Wt[rows][NPad]   (rows = k in chunked order)
+//   mode 0 (forward):        GEMM-k channel = cin,  n = cout, tap as is
+//   mode 1 (backward-data):  GEMM-k channel = cout, n = cin,  tap flipped
+// Row order: chunks of CK k-channels; inside a chunk row = tap * cke + cl (cke = channels
+// actually present in the chunk); every chunk occupies R4 = roundup4(CK*KHW) rows.
+// ------------------------------------------------------------------------------------------
+__global__ void weight_transform_kernel(const float *__restrict__ w, float *__restrict__ wt, int Cout, int Cin,
+                                        int KHW, int mode, int CK, int R4, int rows, int NPad) {
+    const int Ck = mode == 0 ? Cin : Cout;   // channels along GEMM-k
+    const int Nn = mode == 0 ? Cout : Cin;   // GEMM-n extent
+    const long total = (long)rows * NPad;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(e / NPad), n = (int)(e - (long)row * NPad);
+        const int q = row / R4, rr = row - q * R4;
+        const int cke = min(CK, Ck - q * CK);
+        float v = 0.f;
+        if (n < Nn && rr < cke * KHW) {
+            const int tap = rr / cke, cl = rr - tap * cke;
+            const int ck = q * CK + cl;
+            if (mode == 0)
+                v = w[((long)n * Cin + ck) * KHW + tap];
+            else
+                v = w[((long)ck * Cin + n) * KHW + (KHW - 1 - tap)];
+        }
+        wt[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / backward-data MFMA kernel
+// ------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float *x, *x2, *wT, *bias, *scale, *shift, *res;
+    float *y;
+    int N, C1, C2, Hin, Win, up1, H1, W1;
+    int Cout, Hout, Wout;
+    int KH, KW, stride, dil, padT, padL;
+    int act;
+    int lgTC, lgTR;
+    int tilesX, tilesY;
+    int CK, R4;
+    int inRows, inCols, pitch, cplane;
+    int ldw, NPadTotal;
+    int resH, resW, resOff;
+    int vec4;
+    float invImg, invInCols;
+};
+
+// Stage `cke` channels [c0, c0+cke) of the (virtual, concatenated, zero-padded) conv input
+// for the tile whose top-left input coordinate is (iy0, ix0) and first image is n0.
+// LDS layout: [cl][il][row][col] with row pitch `pitch` and channel stride `cplane`.
+struct TileSrc {
+    const float *x, *x2;
+    int N, C1, C2, Hin, Win, up1, H1, W1;
+};
+
+__device__ __forceinline__ void stage_input(float *in_lds, const TileSrc &s, int n0, int iy0, int ix0, int NI,
+                                            int inRows, int inCols, int pitch, int cplane, float invImg,
+                                            float invInCols, int c0, int cke, int tid) {
+    const int imgElems = inRows * inCols;
+    const int planeElems = NI * imgElems;
+    const long cs1 = (long)s.H1 * s.W1, cs2 = (long)s.Hin * s.Win;
+    for (int e = tid; e < planeElems; e += kThreads) {
+        const int il = fast_div(e, invImg);
+        const int rem = e - il * imgElems;
+        const int r = fast_div(rem, invInCols);
+        const int col = rem - r * inCols;
+        const int n = n0 + il, iy = iy0 + r, ix = ix0 + col;
+        const bool ok = n < s.N && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
+        long g1 = 0, g2 = 0;
+        if (ok) {
+            g1 = (long)n * s.C1 * cs1 + (s.up1 ? (long)(iy >> 1) * s.W1 + (ix >> 1) : (long)iy * s.W1 + ix);
+            g2 = (long)n * s.C2 * cs2 + (long)iy * s.Win + ix;
+        }
+        const int lo = (il * inRows + r) * pitch + col;
+        for (int cl = 0; cl < cke; ++cl) {
+            const int c = c0 + cl;
+            float v = 0.f;
+            if (ok) v = c < s.C1 ? s.x[g1 + c * cs1] : s.x2[g2 + (c - s.C1) * cs2];
+            in_lds[cl * cplane + lo] = v;
+        }
+    }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int *koff = reinterpret_cast<int *>(smem);
+    float *in_lds = smem + a.R4;
+    float *w_lds = in_lds + a.CK * a.cplane;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr int TM = 64 * MT;
+    const int lgT = a.lgTC + a.lgTR;
+    const int NI = TM >> lgT;
+    int bid = blockIdx.x;
+    const int tx = bid % a.tilesX;
+    bid /= a.tilesX;
+    const int ty = bid % a.tilesY;
+    const int ig = bid / a.tilesY;
+    const int nb = blockIdx.y;
+    const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
+    const int iy0 = oy0 * a.stride - a.padT, ix0 = ox0 * a.stride - a.padL;
+    const int KHW = a.KH * a.KW, Cin = a.C1 + a.C2;
+    const int TCm = (1 << a.lgTC) - 1, TRm = (1 << a.lgTR) - 1;
+
+    int pixbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int p = (wave * MT + mt) * 16 + l15;
+        const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
+        pixbase[mt] = (il * a.inRows + r * a.stride) * a.pitch + c * a.stride;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    TileSrc src{a.x, a.x2, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1};
+    int cke_prev = -1;
+    for (int c0 = 0; c0 < Cin; c0 += a.CK) {
+        const int cke = min(a.CK, Cin - c0);
+        const int kvalid = cke * KHW;
+        const int kchunk = (kvalid + 3) & ~3;
+        __syncthreads();  // previous chunk fully consumed
+        if (cke != cke_prev) {
+            for (int k = tid; k < kchunk; k += kThreads) {
+                int v = 0;
+                if (k < kvalid) {
+                    const int tap = k / cke, cl = k - tap * cke;
+                    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+                    v = cl * a.cplane + (ky * a.pitch + kx) * a.dil;
+                }
+                koff[k] = v;
+            }
+            cke_prev = cke;
+        }
+        stage_input(in_lds, src, n0, iy0, ix0, NI, a.inRows, a.inCols, a.pitch, a.cplane, a.invImg, a.invInCols,
+                    c0, cke, tid);
+        {
+            const int rowbase = (c0 / a.CK) * a.R4;
+            constexpr int q4 = NT * 4;
+            const float *wsrc = a.wT + (long)rowbase * a.NPadTotal + nb * (NT * 16);
+            for (int e = tid; e < kchunk * q4; e += kThreads) {
+                const int r = e / q4, q = e - r * q4;
+                const float4 v = *reinterpret_cast<const float4 *>(wsrc + (long)r * a.NPadTotal + q * 4);
+                *reinterpret_cast<float4 *>(w_lds + r * a.ldw + q * 4) = v;
+            }
+        }
+        __syncthreads();
+        const int nkq = kchunk >> 2;
+        for (int kq = 0; kq < nkq; ++kq) {
+            const int krow = kq * 4 + lq;
+            const int ko = koff[krow];
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = in_lds[pixbase[mt] + ko];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = w_lds[krow * a.ldw + nt * 16 + l15];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    // epilogue: D layout col(n) = lane&15, row(m) = (lane>>4)*4 + reg
+    const long planeO = (long)a.Hout * a.Wout;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int pb = (wave * MT + mt) * 16 + lq * 4;
+        int n_[4], oy_[4], ox_[4];
+        bool ok_[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = pb + j;
+            const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
+            n_[j] = n0 + il;
+            oy_[j] = oy0 + r;
+            ox_[j] = ox0 + c;
+            ok_[j] = n_[j] < a.N && oy_[j] < a.Hout && ox_[j] < a.Wout;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = nb * (NT * 16) + nt * 16 + l15;
+            if (co >= a.Cout) continue;
+            float sc = 1.f, sh = 0.f;
+            if (a.scale) {
+                sc = a.scale[co];
+                sh = a.shift[co];
+            } else if (a.bias) {
+                sh = a.bias[co];
+            }
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = acc[mt][nt][j];
+                if (a.res && ok_[j])
+                    t += a.res[(((long)n_[j] * a.Cout + co) * a.resH + oy_[j] + a.resOff) * a.resW + ox_[j] + a.resOff];
+                v[j] = apply_act(t * sc + sh, a.act);
+            }
+            if (a.vec4) {
+                if (ok_[0])
+                    *reinterpret_cast<float4 *>(a.y + ((long)n_[0] * a.Cout + co) * planeO + (long)oy_[0] * a.Wout + ox_[0]) =
+                        make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ok_[j]) a.y[((long)n_[j] * a.Cout + co) * planeO + (long)oy_[j] * a.Wout + ox_[j]] = v[j];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward-weight MFMA kernel:  partial[group][Cout][Cin][KHW]
+// ------------------------------------------------------------------------------------------
+struct WgArgs {
+    const float *x, *x2, *gy;
+    float *partial;
+    int N, C1, C2, Hin, Win, up1, H1, W1;
+    int Cout, Hout, Wout;
+    int KH, KW, stride, dil, padT, padL;
+    int lgTC, lgTR;          // 64-pixel tile
+    int tilesX, tilesY, nTiles, tilesPerGroup;
+    int CKW;                 // input channels per blockIdx.y
+    int ioffN;               // ints reserved for the k-row offset table
+    int inRows, inCols, pitch, cplane;
+    int gstride;
+    float invImg, invInCols;
+};
+
+template <int IT, int NT>
+__global__ __launch_bounds__(kThreads) void conv_wgrad_mfma_kernel(const WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int *ioff = reinterpret_cast<int *>(smem);          // [ioffN]
+    int *pixoff = ioff + a.ioffN;                       // [64]
+    float *x_lds = smem + a.ioffN + 64;                 // [CKW * cplane]
+    float *g_lds = x_lds + a.CKW * a.cplane;            // [NT*16 * gstride]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int lgT = a.lgTC + a.lgTR;
+    const int NI = 64 >> lgT;
+    const int TCm = (1 << a.lgTC) - 1, TRm = (1 << a.lgTR) - 1;
+    const int KHW = a.KH * a.KW, Cin = a.C1 + a.C2;
+    const int c0 = blockIdx.y * a.CKW;
+    const int cke = min(a.CKW, Cin - c0);
+    const int kvalid = cke * KHW;
+    const int nIT = (kvalid + 15) >> 4;
+    const int co0 = blockIdx.z * (NT * 16);
+
+    for (int k = tid; k < nIT * 16; k += kThreads) {
+        int v = 0;
+        if (k < kvalid) {
+            const int tap = k / cke, cl = k - tap * cke;
+            const int ky = tap / a.KW, kx = tap - ky * a.KW;
+            v = cl * a.cplane + (ky * a.pitch + kx) * a.dil;
+        }
+        ioff[k] = v;
+    }
+    if (tid < 64) {
+        const int il = tid >> lgT, r = (tid >> a.lgTC) & TRm, c = tid & TCm;
+        pixoff[tid] = (il * a.inRows + r * a.stride) * a.pitch + c * a.stride;
+    }
+    __syncthreads();
+    int ioffv[IT];
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+        const int it = wave + 4 * t;
+        ioffv[t] = it < nIT ? ioff[it * 16 + l15] : 0;
+    }
+    f32x4 acc[IT][NT];
+#pragma unroll
+    for (int t = 0; t < IT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    TileSrc src{a.x, a.x2, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1};
+    const long planeO = (long)a.Hout * a.Wout;
+    const int t_begin = blockIdx.x * a.tilesPerGroup;
+    const int t_end = min(a.nTiles, t_begin + a.tilesPerGroup);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int b = tile;
+        const int tx = b % a.tilesX;
+        b /= a.tilesX;
+        const int ty = b % a.tilesY;
+        const int ig = b / a.tilesY;
+        const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
+        __syncthreads();
+        stage_input(x_lds, src, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, NI, a.inRows, a.inCols,
+                    a.pitch, a.cplane, a.invImg, a.invInCols, c0, cke, tid);
+        for (int e = tid; e < NT * 16 * 64; e += kThreads) {
+            const int col = e >> 6, p = e & 63;
+            const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
+            const int n = n0 + il, oy = oy0 + r, ox = ox0 + c, co = co0 + col;
+            float v = 0.f;
+            if (co < a.Cout && n < a.N && oy < a.Hout && ox < a.Wout)
+                v = a.gy[((long)n * a.Cout + co) * planeO + (long)oy * a.Wout + ox];
+            g_lds[col * a.gstride + p] = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int ks = 0; ks < 16; ++ks) {
+            const int p = ks * 4 + lq;
+            const int po = pixoff[p];
+            float av[IT], bv[NT];
+#pragma unroll
+            for (int t = 0; t < IT; ++t) av[t] = x_lds[ioffv[t] + po];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = g_lds[(nt * 16 + l15) * a.gstride + p];
+#pragma unroll
+            for (int t = 0; t < IT; ++t) {
+                if (wave + 4 * t < nIT) {  // wave-uniform
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[nt], acc[t][nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // write partial: D rows = k (lq*4 + reg), cols = cout (l15)
+    float *dst = a.partial + (long)blockIdx.x * a.Cout * Cin * KHW;
+#pragma unroll
+    for (int t = 0; t < IT; ++t) {
+        const int it = wave + 4 * t;
+        if (it >= nIT) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = it * 16 + lq * 4 + j;
+            if (k >= kvalid) continue;
+            const int tap = k / cke, cl = k - tap * cke;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = co0 + nt * 16 + l15;
+                if (co < a.Cout) dst[((long)co * Cin + c0 + cl) * KHW + tap] = acc[t][nt][j];
+            }
+        }
+    }
+}
+
+__global__ void reduce_partials_kernel(const float *__restrict__ partial, float *__restrict__ out, long n, int groups) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int g = 0; g < groups; ++g) s += partial[(long)g * n + e];
+        out[e] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// direct kernels (plain statement of the maths)
+// ------------------------------------------------------------------------------------------
+struct DirectArgs {
+    const float *x, *x2, *w, *gy;
+    float *y;
+    sprk_conv_geom g;
+    sprk_conv_epilogue ep;
+};
+
+__device__ __forceinline__ float fetch_in(const DirectArgs &a, int n, int c, int iy, int ix) {
+    const sprk_conv_geom &g = a.g;
+    if ((unsigned)iy >= (unsigned)g.Hin || (unsigned)ix >= (unsigned)g.Win) return 0.f;
+    if (c < g.C1) {
+        if (g.up1) return a.x[(((long)n * g.C1 + c) * (g.Hin >> 1) + (iy >> 1)) * (g.Win >> 1) + (ix >> 1)];
+        return a.x[(((long)n * g.C1 + c) * g.Hin + iy) * g.Win + ix];
+    }
+    return a.x2[(((long)n * g.C2 + (c - g.C1)) * g.Hin + iy) * g.Win + ix];
+}
+
+__global__ void conv_fwd_direct_kernel(const DirectArgs a) {
+    const sprk_conv_geom &g = a.g;
+    const int Cin = g.C1 + g.C2;
+    const long total = (long)g.N * g.Cout * g.Hout * g.Wout;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long t = e;
+        const int ox = (int)(t % g.Wout); t /= g.Wout;
+        const int oy = (int)(t % g.Hout); t /= g.Hout;
+        const int co = (int)(t % g.Cout);
+        const int n = (int)(t / g.Cout);
+        float s = 0.f;
+        for (int c = 0; c < Cin; ++c)
+            for (int ky = 0; ky < g.KH; ++ky)
+                for (int kx = 0; kx < g.KW; ++kx)
+                    s += fetch_in(a, n, c, oy * g.stride - g.pad_top + ky * g.dil, ox * g.stride - g.pad_left + kx * g.dil) *
+                         a.w[(((long)co * Cin + c) * g.KH + ky) * g.KW + kx];
+        if (a.ep.res) s += a.ep.res[(((long)n * g.Cout + co) * a.ep.res_h + oy + a.ep.res_off) * a.ep.res_w + ox + a.ep.res_off];
+        if (a.ep.scale)
+            s = s * a.ep.scale[co] + a.ep.shift[co];
+        else if (a.ep.bias)
+            s += a.ep.bias[co];
+        a.y[e] = apply_act(s, a.ep.act);
+    }
+}
+
+// y here is gin [N,Cin,Hin,Win]
+__global__ void conv_bwd_data_direct_kernel(const DirectArgs a) {
+    const sprk_conv_geom &g = a.g;
+    const int Cin = g.C1 + g.C2;
+    const long total = (long)g.N * Cin * g.Hin * g.Win;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long t = e;
+        const int ix = (int)(t % g.Win); t /= g.Win;
+        const int iy = (int)(t % g.Hin); t /= g.Hin;
+        const int c = (int)(t % Cin);
+        const int n = (int)(t / Cin);
+        float s = 0.f;
+        for (int ky = 0; ky < g.KH; ++ky) {
+            const int ny = iy + g.pad_top - ky * g.dil;
+            if (ny < 0 || ny % g.stride) continue;
+            const int oy = ny / g.stride;
+            if (oy >= g.Hout) continue;
+            for (int kx = 0; kx < g.KW; ++kx) {
+                const int nx = ix + g.pad_left - kx * g.dil;
+                if (nx < 0 || nx % g.stride) continue;
+                const int ox = nx / g.stride;
+                if (ox >= g.Wout) continue;
+                for (int co = 0; co < g.Cout; ++co)
+                    s += a.gy[(((long)n * g.Cout + co) * g.Hout + oy) * g.Wout + ox] *
+                         a.w[(((long)co * Cin + c) * g.KH + ky) * g.KW + kx];
+            }
+        }
+        a.y[e] = s;
+    }
+}
+
+// one block per (co, c); y here is gw
+__global__ __launch_bounds__(256) void conv_bwd_weight_direct_kernel(const DirectArgs a) {
+    const sprk_conv_geom &g = a.g;
+    const int Cin = g.C1 + g.C2;
+    const int co = blockIdx.x / Cin, c = blockIdx.x % Cin;
+    __shared__ float red[256];
+    const long npix = (long)g.N * g.Hout * g.Wout;
+    for (int ky = 0; ky < g.KH; ++ky)
+        for (int kx = 0; kx < g.KW; ++kx) {
+            float s = 0.f;
+            for (long p = threadIdx.x; p < npix; p += 256) {
+                long t = p;
+                const int ox = (int)(t % g.Wout); t /= g.Wout;
+                const int oy = (int)(t % g.Hout);
+                const int n = (int)(t / g.Hout);
+                s += fetch_in(a, n, c, oy * g.stride - g.pad_top + ky * g.dil, ox * g.stride - g.pad_left + kx * g.dil) *
+                     a.gy[(((long)n * g.Cout + co) * g.Hout + oy) * g.Wout + ox];
+            }
+            red[threadIdx.x] = s;
+            __syncthreads();
+            for (int w = 128; w > 0; w >>= 1) {
+                if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) a.y[(((long)co * Cin + c) * g.KH + ky) * g.KW + kx] = red[0];
+            __syncthreads();
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// activation backward (+ bias gradient) and concat/upsample gradient split
+// ------------------------------------------------------------------------------------------
+// grid (C, nsplit): block (c, s) walks images n = s, s+nsplit, ... of channel c.
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const float *__restrict__ y, float *gpre,
+                                                      float *__restrict__ partial, int act, int N, int C, int HW,
+                                                      int nsplit) {
+    const int c = blockIdx.x, s = blockIdx.y;
+    float sum = 0.f;
+    for (int n = s; n < N; n += nsplit) {
+        const long base = ((long)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float v = g[base + i];
+            if (act == SPRK_ACT_LEAKY)
+                v = y[base + i] > 0.f ? v : v * kLeak;
+            else if (act == SPRK_ACT_RELU)
+                v = y[base + i] > 0.f ? v : 0.f;
+            if (act != SPRK_ACT_NONE) gpre[base + i] = v;
+            sum += v;
+        }
+    }
+    if (partial) {
+        __shared__ float red[256];
+        red[threadIdx.x] = sum;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[c * nsplit + s] = red[0];
+    }
+}
+
+__global__ void bias_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gb, int C, int nsplit) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int i = 0; i < nsplit; ++i) s += partial[c * nsplit + i];
+    gb[c] = s;
+}
+
+__global__ void concat_up_bwd_kernel(const float *__restrict__ gin, float *__restrict__ ga, float *__restrict__ gb,
+                                     int N, int C1, int C2, int H, int W, int up1) {
+    const int Cin = C1 + C2;
+    const int H1 = up1 ? H >> 1 : H, W1 = up1 ? W >> 1 : W;
+    const long nA = (long)N * C1 * H1 * W1, nB = (long)N * C2 * H * W;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nA + nB; e += (long)gridDim.x * blockDim.x) {
+        if (e < nA) {
+            long t = e;
+            const int x = (int)(t % W1); t /= W1;
+            const int y = (int)(t % H1); t /= H1;
+            const int c = (int)(t % C1);
+            const int n = (int)(t / C1);
+            const float *p = gin + (((long)n * Cin + c) * H) * W;
+            float v;
+            if (up1) {
+                const float *q = p + (long)(2 * y) * W + 2 * x;
+                v = (q[0] + q[1]) + (q[W] + q[W + 1]);
+            } else {
+                v = p[(long)y * W + x];
+            }
+            ga[e] = v;
+        } else {
+            long t = e - nA;
+            const int x = (int)(t % W); t /= W;
+            const int y = (int)(t % H); t /= H;
+            const int c = (int)(t % C2);
+            const int n = (int)(t / C2);
+            gb[e - nA] = gin[(((long)n * Cin + C1 + c) * H + y) * W + x];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side planning
+// ------------------------------------------------------------------------------------------
+struct FwdPlan {
+    int MT, NT, lgTC, lgTR, tilesX, tilesY, imgGroups, nblkN;
+    int CK, R4, rows, NPadTotal;
+    int inRows, inCols, pitch, cplane, ldw;
+    size_t ldsBytes;
+};
+
+int pad_to_residue(int raw, int residue) {  // smallest v >= raw with v % 32 == residue
+    return raw + ((residue - raw % 32) + 32) % 32;
+}
+
+// Ck: channels along GEMM-k; Nn: GEMM-n extent; output spatial dims Ho x Wo over Nimg images
+bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stride, int dil, FwdPlan *p) {
+    const int KHW = KH * KW;
+    const int ntile = sprk::cdiv(Nn, 16);
+    int NT = 1;
+    for (int cand : {6, 4, 3, 2, 1})
+        if (ntile % cand == 0) {
+            NT = cand;
+            break;
+        }
+    int MT = 4;
+    auto geometry = [&](int mt, int nt) {
+        const int TM = 64 * mt;
+        int TC = std::min(sprk::pow2_ceil(Wo), 64);
+        if (dil * (KW - 1) >= 8 && TM >= 256) TC = std::min(TC, 16);
+        TC = std::min(TC, TM);
+        int TR = std::min(TM / TC, sprk::pow2_ceil(Ho));
+        int NI = TM / (TC * TR);
+        p->MT = mt;
+        p->NT = nt;
+        p->lgTC = sprk::ilog2(TC);
+        p->lgTR = sprk::ilog2(TR);
+        p->tilesX = sprk::cdiv(Wo, TC);
+        p->tilesY = sprk::cdiv(Ho, TR);
+        p->imgGroups = sprk::cdiv(Nimg, NI);
+        p->nblkN = ntile / nt;
+        p->inRows = (TR - 1) * stride + (KH - 1) * dil + 1;
+        p->inCols = (TC - 1) * stride + (KW - 1) * dil + 1;
+        p->pitch = p->inCols;
+        p->cplane = pad_to_residue(NI * p->inRows * p->pitch, 16);
+        return (long)p->imgGroups * p->tilesX * p->tilesY * p->nblkN;
+    };
+    long blocks = geometry(MT, NT);
+    while (blocks < 512 && MT > 1) {
+        MT >>= 1;
+        blocks = geometry(MT, NT);
+    }
+    while (blocks < 512 && NT > 1) {
+        NT = (NT == 6) ? 3 : (NT == 4) ? 2 : 1;
+        blocks = geometry(MT, NT);
+    }
+    p->ldw = (NT % 2) ? NT * 16 : NT * 16 + 16;
+    p->NPadTotal = ntile * 16;
+    int CK = std::max(1, std::min(Ck, KHW == 1 ? 32 : std::max(1, 72 / KHW)));
+    auto lds = [&](int ck) {
+        const int r4 = sprk::roundup(ck * KHW, 4);
+        return (size_t)(r4 + ck * p->cplane + r4 * p->ldw) * 4;
+    };
+    while (CK > 1 && lds(CK) > 64 * 1024) CK >>= 1;
+    if (lds(CK) > 64 * 1024) return false;
+    p->CK = CK;
+    p->R4 = sprk::roundup(CK * KHW, 4);
+    p->rows = sprk::cdiv(Ck, CK) * p->R4;
+    p->ldsBytes = lds(CK);
+    return true;
+}
+
+template <int MT>
+void launch_fwd_nt(const ConvArgs &a, const FwdPlan &p, dim3 grid, hipStream_t s) {
+    switch (p.NT) {
+        case 1: hipLaunchKernelGGL((conv_mfma_kernel<MT, 1>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+        case 2: hipLaunchKernelGGL((conv_mfma_kernel<MT, 2>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+        case 3: hipLaunchKernelGGL((conv_mfma_kernel<MT, 3>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+        case 4: hipLaunchKernelGGL((conv_mfma_kernel<MT, 4>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+        default: hipLaunchKernelGGL((conv_mfma_kernel<MT, 6>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+    }
+}
+
+void launch_fwd(const ConvArgs &a, const FwdPlan &p, hipStream_t s) {
+    dim3 grid(p.imgGroups * p.tilesX * p.tilesY, p.nblkN);
+    switch (p.MT) {
+        case 1: launch_fwd_nt<1>(a, p, grid, s); break;
+        case 2: launch_fwd_nt<2>(a, p, grid, s); break;
+        default: launch_fwd_nt<4>(a, p, grid, s); break;
+    }
+}
+
+void fill_args(ConvArgs &a, const FwdPlan &p) {
+    a.lgTC = p.lgTC;
+    a.lgTR = p.lgTR;
+    a.tilesX = p.tilesX;
+    a.tilesY = p.tilesY;
+    a.CK = p.CK;
+    a.R4 = p.R4;
+    a.inRows = p.inRows;
+    a.inCols = p.inCols;
+    a.pitch = p.pitch;
+    a.cplane = p.cplane;
+    a.ldw = p.ldw;
+    a.NPadTotal = p.NPadTotal;
+    a.invImg = 1.0f / (float)(p.inRows * p.inCols);
+    a.invInCols = 1.0f / (float)p.inCols;
+}
+
+int check_geom(const sprk_conv_geom *g) {
+    SPRK_REQUIRE(g, "conv: null geometry");
+    SPRK_REQUIRE(g->N > 0 && g->C1 >= 0 && g->C2 >= 0 && g->C1 + g->C2 > 0 && g->Cout > 0, "conv: bad channel/batch counts");
+    SPRK_REQUIRE(g->Hin > 0 && g->Win > 0 && g->Hout > 0 && g->Wout > 0, "conv: bad spatial dims");
+    SPRK_REQUIRE(g->KH > 0 && g->KW > 0 && g->stride > 0 && g->dil > 0, "conv: bad kernel params");
+    SPRK_REQUIRE(!g->up1 || (g->Hin % 2 == 0 && g->Win % 2 == 0), "conv: up1 needs even Hin/Win");
+    // the last output row/col must start inside the padded input (no reads needed beyond zero fill is fine)
+    SPRK_REQUIRE((long)g->N * (g->C1 + g->C2) * g->Hin * g->Win < (1L << 40), "conv: tensor too large");
+    return SPRK_OK;
+}
+
+struct WgPlan {
+    int IT, NT, lgTC, lgTR, tilesX, tilesY, nTiles, tilesPerGroup, groups;
+    int CKW, nChunks, nblkN, ioffN;
+    int inRows, inCols, pitch, cplane, gstride;
+    size_t ldsBytes;
+};
+
+bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
+    const int KHW = g->KH * g->KW, Cin = g->C1 + g->C2;
+    const int ntile = sprk::cdiv(g->Cout, 16);
+    int NT = 1;
+    for (int cand : {6, 4, 3, 2, 1})
+        if (ntile % cand == 0) {
+            NT = cand;
+            break;
+        }
+    p->NT = NT;
+    p->nblkN = ntile / NT;
+    const int TM = 64;
+    int TC = std::min(sprk::pow2_ceil(g->Wout), 64);
+    if (g->dil * (g->KW - 1) >= 8) TC = std::min(TC, 8);
+    int TR = std::min(TM / TC, sprk::pow2_ceil(g->Hout));
+    int NI = TM / (TC * TR);
+    p->lgTC = sprk::ilog2(TC);
+    p->lgTR = sprk::ilog2(TR);
+    p->tilesX = sprk::cdiv(g->Wout, TC);
+    p->tilesY = sprk::cdiv(g->Hout, TR);
+    p->nTiles = sprk::cdiv(g->N, NI) * p->tilesX * p->tilesY;
+    p->inRows = (TR - 1) * g->stride + (g->KH - 1) * g->dil + 1;
+    p->inCols = (TC - 1) * g->stride + (g->KW - 1) * g->dil + 1;
+    p->pitch = p->inCols;
+    p->cplane = pad_to_residue(NI * p->inRows * p->pitch, 2);
+    p->gstride = 66;
+    // channels per chunk: up to 20 k-tiles of 16 rows (IT = 5 per wave)
+    int CKW = std::max(1, std::min(Cin, (5 * 4 * 16) / KHW));
+    if (KHW == 9) CKW = std::min(CKW, 32);
+    if (KHW == 1) CKW = std::min(CKW, 128);
+    auto lds = [&](int ck) {
+        const int ioffN = sprk::roundup(sprk::roundup(ck * KHW, 16), 4);
+        return (size_t)(ioffN + 64 + ck * p->cplane + NT * 16 * p->gstride) * 4;
+    };
+    while (CKW > 1 && lds(CKW) > 64 * 1024) CKW = (CKW + 1) / 2;
+    if (lds(CKW) > 64 * 1024) return false;
+    p->CKW = CKW;
+    p->nChunks = sprk::cdiv(Cin, CKW);
+    p->ioffN = sprk::roundup(sprk::roundup(CKW * KHW, 16), 4);
+    const int nIT = sprk::cdiv(std::min(CKW, Cin) * KHW, 16);
+    const int itw = sprk::cdiv(nIT, 4);
+    p->IT = itw <= 1 ? 1 : itw <= 2 ? 2 : itw <= 3 ? 3 : 5;
+    if (itw > 5) return false;
+    p->ldsBytes = lds(CKW);
+    const int per = p->nChunks * p->nblkN;
+    int groups = std::max(1, std::min(p->nTiles, sprk::cdiv(1024, per)));
+    p->tilesPerGroup = sprk::cdiv(p->nTiles, groups);
+    p->groups = sprk::cdiv(p->nTiles, p->tilesPerGroup);
+    return true;
+}
+
+template <int IT>
+void launch_wg_nt(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
+    switch (p.NT) {
+        case 1: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, 1>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+        case 2: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, 2>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+        case 3: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, 3>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+        case 4: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, 4>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+        default: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, 6>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+    }
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+size_t sprk_conv2d_fwd_ws_bytes(const sprk_conv_geom *g) {
+    if (!g) return 0;
+    FwdPlan p;
+    if (!plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, &p)) return 0;
+    return (size_t)p.rows * p.NPadTotal * sizeof(float);
+}
+
+int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, const sprk_conv_geom *g,
+                    const sprk_conv_epilogue *ep, void *ws, size_t ws_bytes, void *stream) {
+    if (int rc = check_geom(g)) return rc;
+    SPRK_REQUIRE(x && w && y, "conv2d_fwd: null tensor");
+    SPRK_REQUIRE(g->C2 == 0 || x2, "conv2d_fwd: C2 > 0 but x2 is null");
+    hipStream_t s = (hipStream_t)stream;
+    sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE};
+    if (!ep) ep = &e0;
+    SPRK_REQUIRE(!ep->scale || ep->shift, "conv2d_fwd: scale without shift");
+    if (sprk::g_naive) {
+        DirectArgs a{x, x2, w, nullptr, y, *g, *ep};
+        const long total = (long)g->N * g->Cout * g->Hout * g->Wout;
+        hipLaunchKernelGGL(conv_fwd_direct_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, s, a);
+        return sprk::check_launch("conv_fwd_direct");
+    }
+    FwdPlan p;
+    SPRK_REQUIRE(plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, &p),
+                 "conv2d_fwd: geometry does not fit LDS");
+    const size_t need = (size_t)p.rows * p.NPadTotal * sizeof(float);
+    if (ws_bytes < need || !ws) {
+        sprk::set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
+        return SPRK_EWORKSPACE;
+    }
+    float *wT = (float *)ws;
+    hipLaunchKernelGGL(weight_transform_kernel, dim3(sprk::ew_blocks((long)p.rows * p.NPadTotal)), dim3(256), 0, s, w,
+                       wT, g->Cout, g->C1 + g->C2, g->KH * g->KW, 0, p.CK, p.R4, p.rows, p.NPadTotal);
+    if (int rc = sprk::check_launch("weight_transform")) return rc;
+    ConvArgs a{};
+    a.x = x; a.x2 = x2; a.wT = wT; a.bias = ep->bias; a.scale = ep->scale; a.shift = ep->shift; a.res = ep->res;
+    a.y = y;
+    a.N = g->N; a.C1 = g->C1; a.C2 = g->C2; a.Hin = g->Hin; a.Win = g->Win; a.up1 = g->up1;
+    a.H1 = g->up1 ? g->Hin / 2 : g->Hin;
+    a.W1 = g->up1 ? g->Win / 2 : g->Win;
+    a.Cout = g->Cout; a.Hout = g->Hout; a.Wout = g->Wout;
+    a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.dil = g->dil; a.padT = g->pad_top; a.padL = g->pad_left;
+    a.act = ep->act;
+    a.resH = ep->res_h; a.resW = ep->res_w; a.resOff = ep->res_off;
+    fill_args(a, p);
+    a.vec4 = (g->Wout % 4 == 0) && (p.lgTC >= 2) && (((uintptr_t)y & 15) == 0);
+    const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * g->KH * g->KW;
+    sprk::prof_begin(0, flops, s);
+    launch_fwd(a, p, s);
+    sprk::prof_end(0, s);
+    return sprk::check_launch("conv_mfma");
+}
+
+size_t sprk_conv2d_bwd_data_ws_bytes(const sprk_conv_geom *g) {
+    if (!g || g->stride != 1) return 0;
+    FwdPlan p;
+    if (!plan_fwd(g->N, g->Cout, g->C1 + g->C2, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, &p)) return 0;
+    return (size_t)p.rows * p.NPadTotal * sizeof(float);
+}
+
+int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk_conv_geom *g, void *ws,
+                         size_t ws_bytes, void *stream) {
+    if (int rc = check_geom(g)) return rc;
+    SPRK_REQUIRE(gy && w && gin, "conv2d_bwd_data: null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const int Cin = g->C1 + g->C2;
+    if (sprk::g_naive || g->stride != 1) {
+        sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE};
+        DirectArgs a{nullptr, nullptr, w, gy, gin, *g, e0};
+        const long total = (long)g->N * Cin * g->Hin * g->Win;
+        hipLaunchKernelGGL(conv_bwd_data_direct_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, s, a);
+        return sprk::check_launch("conv_bwd_data_direct");
+    }
+    // gin = correlation of gy with the flipped, channel-transposed kernel
+    FwdPlan p;
+    SPRK_REQUIRE(plan_fwd(g->N, g->Cout, Cin, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, &p),
+                 "conv2d_bwd_data: geometry does not fit LDS");
+    const size_t need = (size_t)p.rows * p.NPadTotal * sizeof(float);
+    if (ws_bytes < need || !ws) {
+        sprk::set_error("conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
+        return SPRK_EWORKSPACE;
+    }
+    float *wT = (float *)ws;
+    hipLaunchKernelGGL(weight_transform_kernel, dim3(sprk::ew_blocks((long)p.rows * p.NPadTotal)), dim3(256), 0, s, w,
+                       wT, g->Cout, Cin, g->KH * g->KW, 1, p.CK, p.R4, p.rows, p.NPadTotal);
+    if (int rc = sprk::check_launch("weight_transform")) return rc;
+    ConvArgs a{};
+    a.x = gy; a.x2 = nullptr; a.wT = wT; a.y = gin;
+    a.N = g->N; a.C1 = g->Cout; a.C2 = 0; a.Hin = g->Hout; a.Win = g->Wout; a.up1 = 0;
+    a.H1 = g->Hout; a.W1 = g->Wout;
+    a.Cout = Cin; a.Hout = g->Hin; a.Wout = g->Win;
+    a.KH = g->KH; a.KW = g->KW; a.stride = 1; a.dil = g->dil;
+    a.padT = (g->KH - 1) * g->dil - g->pad_top;
+    a.padL = (g->KW - 1) * g->dil - g->pad_left;
+    a.act = SPRK_ACT_NONE;
+    fill_args(a, p);
+    a.vec4 = (g->Win % 4 == 0) && (p.lgTC >= 2) && (((uintptr_t)gin & 15) == 0);
+    const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * g->KH * g->KW;
+    sprk::prof_begin(0, flops, s);
+    launch_fwd(a, p, s);
+    sprk::prof_end(0, s);
+    return sprk::check_launch("conv_mfma(bwd_data)");
+}
+
+size_t sprk_conv2d_bwd_weight_ws_bytes(const sprk_conv_geom *g) {
+    if (!g) return 0;
+    WgPlan p;
+    if (!plan_wgrad(g, &p)) return 0;
+    return (size_t)p.groups * g->Cout * (g->C1 + g->C2) * g->KH * g->KW * sizeof(float);
+}
+
+int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, float *gw, const sprk_conv_geom *g,
+                           void *ws, size_t ws_bytes, void *stream) {
+    if (int rc = check_geom(g)) return rc;
+    SPRK_REQUIRE(x && gy && gw, "conv2d_bwd_weight: null tensor");
+    SPRK_REQUIRE(g->C2 == 0 || x2, "conv2d_bwd_weight: C2 > 0 but x2 is null");
+    hipStream_t s = (hipStream_t)stream;
+    const int Cin = g->C1 + g->C2;
+    WgPlan p;
+    const bool ok = plan_wgrad(g, &p);
+    if (sprk::g_naive || !ok) {
+        sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE};
+        DirectArgs a{x, x2, nullptr, gy, gw, *g, e0};
+        hipLaunchKernelGGL(conv_bwd_weight_direct_kernel, dim3(g->Cout * Cin), dim3(256), 0, s, a);
+        return sprk::check_launch("conv_bwd_weight_direct");
+    }
+    const long nW = (long)g->Cout * Cin * g->KH * g->KW;
+    const size_t need = (size_t)p.groups * nW * sizeof(float);
+    if (ws_bytes < need || !ws) {
+        sprk::set_error("conv2d_bwd_weight: workspace %zu < %zu", ws_bytes, need);
+        return SPRK_EWORKSPACE;
+    }
+    WgArgs a{};
+    a.x = x; a.x2 = x2; a.gy = gy; a.partial = (float *)ws;
+    a.N = g->N; a.C1 = g->C1; a.C2 = g->C2; a.Hin = g->Hin; a.Win = g->Win; a.up1 = g->up1;
+    a.H1 = g->up1 ? g->Hin / 2 : g->Hin;
+    a.W1 = g->up1 ? g->Win / 2 : g->Win;
+    a.Cout = g->Cout; a.Hout = g->Hout; a.Wout = g->Wout;
+    a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.dil = g->dil; a.padT = g->pad_top; a.padL = g->pad_left;
+    a.lgTC = p.lgTC; a.lgTR = p.lgTR; a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.nTiles = p.nTiles;
+    a.tilesPerGroup = p.tilesPerGroup;
+    a.CKW = p.CKW; a.ioffN = p.ioffN;
+    a.inRows = p.inRows; a.inCols = p.inCols; a.pitch = p.pitch; a.cplane = p.cplane; a.gstride = p.gstride;
+    a.invImg = 1.0f / (float)(p.inRows * p.inCols);
+    a.invInCols = 1.0f / (float)p.inCols;
+    dim3 grid(p.groups, p.nChunks, p.nblkN);
+    const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * g->KH * g->KW;
+    sprk::prof_begin(1, flops, s);
+    switch (p.IT) {
+        case 1: launch_wg_nt<1>(a, p, grid, s); break;
+        case 2: launch_wg_nt<2>(a, p, grid, s); break;
+        case 3: launch_wg_nt<3>(a, p, grid, s); break;
+        default: launch_wg_nt<5>(a, p, grid, s); break;
+    }
+    sprk::prof_end(1, s);
+    if (int rc = sprk::check_launch("conv_wgrad_mfma")) return rc;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(sprk::ew_blocks(nW)), dim3(256), 0, s, (const float *)ws, gw, nW,
+                       p.groups);
+    return sprk::check_launch("reduce_partials");
+}
+
+static int act_nsplit(int N, int C) {
+    int ns = 1;
+    while (ns < N && (long)C * ns < 1024) ns <<= 1;
+    return std::min(ns, N);
+}
+
+size_t sprk_act_bwd_ws_bytes(int N, int C, int HW) {
+    (void)HW;
+    return (size_t)C * act_nsplit(N, C) * sizeof(float);
+}
+
+int sprk_act_bwd(const float *g, const float *y, float *gpre, float *gbias, int act, int N, int C, int HW, void *ws,
+                 size_t ws_bytes, void *stream) {
+    SPRK_REQUIRE(g && N > 0 && C > 0 && HW > 0, "act_bwd: bad arguments");
+    SPRK_REQUIRE(act == SPRK_ACT_NONE || (y && gpre), "act_bwd: activation needs the saved output and gpre");
+    hipStream_t s = (hipStream_t)stream;
+    if (act == SPRK_ACT_NONE && !gbias) return SPRK_OK;
+    const int ns = act_nsplit(N, C);
+    if (gbias && (ws_bytes < (size_t)C * ns * sizeof(float) || !ws)) {
+        sprk::set_error("act_bwd: workspace too small");
+        return SPRK_EWORKSPACE;
+    }
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(C, ns), dim3(256), 0, s, g, y, gpre, gbias ? (float *)ws : nullptr, act, N, C, HW,
+                       ns);
+    if (int rc = sprk::check_launch("act_bwd")) return rc;
+    if (gbias) {
+        hipLaunchKernelGGL(bias_reduce_kernel, dim3(sprk::cdiv(C, 64)), dim3(64), 0, s, (const float *)ws, gbias, C, ns);
+        return sprk::check_launch("bias_reduce");
+    }
+    return SPRK_OK;
+}
+
+int sprk_concat_up_bwd(const float *gin, float *ga, float *gb, int N, int C1, int C2, int H, int W, int up1,
+                       void *stream) {
+    SPRK_REQUIRE(gin && N > 0 && C1 >= 0 && C2 >= 0 && H > 0 && W > 0, "concat_up_bwd: bad arguments");
+    SPRK_REQUIRE((C1 == 0 || ga) && (C2 == 0 || gb), "concat_up_bwd: null output");
+    SPRK_REQUIRE(!up1 || (H % 2 == 0 && W % 2 == 0), "concat_up_bwd: odd size with upsampling");
+    const long total = (long)N * C1 * (up1 ? (H / 2) * (W / 2) : H * W) + (long)N * C2 * H * W;
+    hipLaunchKernelGGL(concat_up_bwd_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, gin, ga,
+                       gb, N, C1, C2, H, W, up1);
+    return sprk::check_launch("concat_up_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,378 @@
+// HBM-bound plumbing kernels of the blind-spot U-Net and the per-pixel pipeline maths.
+// Every kernel reads each input element once and writes each output element once
+// (coalesced along x); none of them is reshaped into a GEMM.
+#include "common.h"
+
+namespace {
+
+// ---- Shift2d((shift,0)) + MaxPool2d(2) -------------------------------------------------------
+// xs = x shifted down by `shift` rows (zeros on top, last rows dropped); y = 2x2/2 max of xs.
+__device__ __forceinline__ float shifted(const float *p, int u, int v, int W, int shift) {
+    const int r = u - shift;
+    return r >= 0 ? p[(long)r * W + v] : 0.f;
+}
+
+__global__ void shift_maxpool2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int NC, int H, int W,
+                                          int shift) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)NC * Ho * Wo;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long t = e;
+        const int j = (int)(t % Wo); t /= Wo;
+        const int i = (int)(t % Ho);
+        const long nc = t / Ho;
+        const float *p = x + nc * H * W;
+        float m = shifted(p, 2 * i, 2 * j, W, shift);
+        float v = shifted(p, 2 * i, 2 * j + 1, W, shift);
+        if (v > m || v != v) m = v;
+        v = shifted(p, 2 * i + 1, 2 * j, W, shift);
+        if (v > m || v != v) m = v;
+        v = shifted(p, 2 * i + 1, 2 * j + 1, W, shift);
+        if (v > m || v != v) m = v;
+        y[e] = m;
+    }
+}
+
+// one thread per x element: it receives the window's gradient iff it is the FIRST maximum of
+// its window in row-major order (torch's max_pool2d backward rule).
+__global__ void shift_maxpool2_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x,
+                                          float *__restrict__ gx, int NC, int H, int W, int shift) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)NC * H * W;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long t = e;
+        const int v0 = (int)(t % W); t /= W;
+        const int r0 = (int)(t % H);
+        const long nc = t / H;
+        const int u = r0 + shift;  // row in the shifted image
+        float g = 0.f;
+        if (u < 2 * Ho && v0 < 2 * Wo) {
+            const int i = u >> 1, j = v0 >> 1;
+            const float *p = x + nc * H * W;
+            int best = 0;
+            float m = shifted(p, 2 * i, 2 * j, W, shift);
+#pragma unroll
+            for (int k = 1; k < 4; ++k) {
+                const float v = shifted(p, 2 * i + (k >> 1), 2 * j + (k & 1), W, shift);
+                if (v > m || v != v) {
+                    m = v;
+                    best = k;
+                }
+            }
+            const int mine = ((u & 1) << 1) | (v0 & 1);
+            if (best == mine) g = gy[(nc * Ho + i) * Wo + j];
+        }
+        gx[e] = g;
+    }
+}
+
+// ---- rotations -------------------------------------------------------------------------------
+// clockwise rotation R_k (k*90 degrees) of a PxP plane: out[i][j] = in[src(i,j)]
+__device__ __forceinline__ void rot_src(int k, int i, int j, int P, int &u, int &v) {
+    switch (k) {
+        case 0: u = i; v = j; break;
+        case 1: u = j; v = P - 1 - i; break;           // 90
+        case 2: u = P - 1 - i; v = P - 1 - j; break;   // 180
+        default: u = P - 1 - j; v = i; break;          // 270
+    }
+}
+// inverse: given a source position (u,v) return the output position (i,j) it lands on
+__device__ __forceinline__ void rot_dst(int k, int u, int v, int P, int &i, int &j) {
+    switch (k) {
+        case 0: i = u; j = v; break;
+        case 1: i = P - 1 - v; j = u; break;
+        case 2: i = P - 1 - u; j = P - 1 - v; break;
+        default: i = v; j = P - 1 - u; break;
+    }
+}
+
+__global__ void rot4_stack_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int B, int C, int P) {
+    const long plane = (long)P * P, per = (long)B * C * plane, total = 4 * per;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(e / per);
+        long t = e - k * per;
+        const int j = (int)(t % P); t /= P;
+        const int i = (int)(t % P);
+        const long bc = t / P;
+        int u, v;
+        rot_src(k, i, j, P, u, v);
+        y[e] = x[bc * plane + (long)u * P + v];
+    }
+}
+
+__global__ void rot4_stack_bwd_kernel(const float *__restrict__ gy, float *__restrict__ gx, int B, int C, int P) {
+    const long plane = (long)P * P, per = (long)B * C * plane;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (long)gridDim.x * blockDim.x) {
+        long t = e;
+        const int v = (int)(t % P); t /= P;
+        const int u = (int)(t % P);
+        const long bc = t / P;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int i, j;
+            rot_dst(k, u, v, P, i, j);
+            s += gy[k * per + bc * plane + (long)i * P + j];
+        }
+        gx[e] = s;
+    }
+}
+
+// f[b, k*C + c, i, j] = R_{a_k}( shift_down_1( d[k*B + b, c] ) )[i, j],  a = (0, 270, 180, 90)
+__global__ void unrot4_fwd_kernel(const float *__restrict__ d, float *__restrict__ f, int B, int C, int P) {
+    const long plane = (long)P * P, total = (long)B * 4 * C * plane;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long t = e;
+        const int j = (int)(t % P); t /= P;
+        const int i = (int)(t % P); t /= P;
+        const int kc = (int)(t % (4 * C));
+        const int b = (int)(t / (4 * C));
+        const int k = kc / C, c = kc - k * C;
+        int u, v;
+        rot_src((4 - k) & 3, i, j, P, u, v);
+        float val = 0.f;
+        if (u >= 1) val = d[(((long)k * B + b) * C + c) * plane + (long)(u - 1) * P + v];
+        f[e] = val;
+    }
+}
+
+__global__ void unrot4_bwd_kernel(const float *__restrict__ gf, float *__restrict__ gd, int B, int C, int P) {
+    const long plane = (long)P * P, total = (long)4 * B * C * plane;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long t = e;
+        const int v = (int)(t % P); t /= P;
+        const int s = (int)(t % P); t /= P;
+        const int c = (int)(t % C); t /= C;
+        const int b = (int)(t % B);
+        const int k = (int)(t / B);
+        float g = 0.f;
+        if (s + 1 < P) {
+            int i, j;
+            rot_dst((4 - k) & 3, s + 1, v, P, i, j);
+            g = gf[(((long)b * 4 + k) * C + c) * plane + (long)i * P + j];
+        }
+        gd[e] = g;
+    }
+}
+
+// ---- reparameterisation, sigmoid --------------------------------------------------------------
+__global__ void reparam_fwd_kernel(const float *__restrict__ o, const float *__restrict__ eps, float *__restrict__ z,
+                                   int B, int HW) {
+    const long total = (long)B * HW;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long b = e / HW, i = e - b * HW;
+        const float mu = o[(2 * b) * HW + i], a = o[(2 * b + 1) * HW + i];
+        z[e] = mu + eps[e] * (a * a);
+    }
+}
+
+__global__ void reparam_bwd_kernel(const float *__restrict__ gz, const float *__restrict__ o,
+                                   const float *__restrict__ eps, float *__restrict__ go, int B, int HW) {
+    const long total = (long)B * HW;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long b = e / HW, i = e - b * HW;
+        const float g = gz[e], a = o[(2 * b + 1) * HW + i];
+        go[(2 * b) * HW + i] = g;
+        go[(2 * b + 1) * HW + i] = g * eps[e] * 2.f * a;
+    }
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void sigmoid_clamp_fwd_kernel(const float *__restrict__ x, float *__restrict__ p, long n) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const float s = sigmoidf(x[e]);
+        p[e] = fminf(fmaxf(s, 1e-4f), 1.f - 1e-4f);
+    }
+}
+
+__global__ void sigmoid_clamp_bwd_kernel(const float *__restrict__ gp, const float *__restrict__ x,
+                                         float *__restrict__ gx, long n) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+        const float s = sigmoidf(x[e]);
+        const bool pass = s >= 1e-4f && s <= 1.f - 1e-4f;  // torch.clamp passes the gradient on [min, max]
+        gx[e] = pass ? gp[e] * s * (1.f - s) : 0.f;
+    }
+}
+
+// ---- SSDN gaussian likelihood -------------------------------------------------------------------
+constexpr int kSsdnBlk = 256;
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = kSsdnBlk / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// grid (nblk, B); partial[b*nblk + blk] = sum of nll over the block's pixels
+__global__ __launch_bounds__(kSsdnBlk) void ssdn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ o,
+                                                            const float *__restrict__ ns, float *__restrict__ partial,
+                                                            float *__restrict__ pme, float *__restrict__ mstd, int HW) {
+    __shared__ float red[kSsdnBlk];
+    const int b = blockIdx.y;
+    const float s = ns[b], vn = s * s;
+    float acc = 0.f;
+    for (int i = blockIdx.x * kSsdnBlk + threadIdx.x; i < HW; i += gridDim.x * kSsdnBlk) {
+        const float xv = x[(long)b * HW + i];
+        const float mu = o[(long)(2 * b) * HW + i], a = o[(long)(2 * b + 1) * HW + i];
+        const float vx = a * a, vy = vx + vn, dd = xv - mu;
+        acc += dd * dd / vy + logf(vy) - 0.05f * s;
+        if (pme) pme[(long)b * HW + i] = (xv * vx + mu * vn) / (vx + vn);
+        if (mstd) mstd[(long)b * HW + i] = sqrtf(vx);
+    }
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[b * gridDim.x + blockIdx.x] = tot;
+}
+
+__global__ void ssdn_finish_kernel(const float *__restrict__ partial, float *__restrict__ out, int B, int nblk,
+                                   float scale) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int i = 0; i < nblk; ++i) s += partial[b * nblk + i];
+    out[b] = s * scale;
+}
+
+__global__ __launch_bounds__(kSsdnBlk) void ssdn_bwd_kernel(const float *__restrict__ gl, const float *__restrict__ x,
+                                                            const float *__restrict__ o, const float *__restrict__ ns,
+                                                            float *__restrict__ go, float *__restrict__ partial, int HW) {
+    __shared__ float red[kSsdnBlk];
+    const int b = blockIdx.y;
+    const float s = ns[b], vn = s * s;
+    const float g = gl[b] / (float)HW;
+    float acc = 0.f;
+    for (int i = blockIdx.x * kSsdnBlk + threadIdx.x; i < HW; i += gridDim.x * kSsdnBlk) {
+        const float xv = x[(long)b * HW + i];
+        const float mu = o[(long)(2 * b) * HW + i], a = o[(long)(2 * b + 1) * HW + i];
+        const float vy = a * a + vn, dd = xv - mu;
+        const float dvy = 1.f / vy - dd * dd / (vy * vy);  // d nll / d var_y
+        go[(long)(2 * b) * HW + i] = g * (-2.f * dd / vy);
+        go[(long)(2 * b + 1) * HW + i] = g * dvy * 2.f * a;
+        acc += dvy * 2.f * s - 0.05f;
+    }
+    const float tot = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[b * gridDim.x + blockIdx.x] = tot * g;
+}
+
+int ssdn_nblk(int HW) { return std::max(1, std::min(64, sprk::cdiv(HW, kSsdnBlk * 4))); }
+
+}  // namespace
+
+extern "C" {
+
+int sprk_shift_maxpool2_fwd(const float *x, float *y, int NC, int H, int W, int shift, void *stream) {
+    SPRK_REQUIRE(x && y && NC > 0 && H >= 2 && W >= 2 && shift >= 0, "shift_maxpool2_fwd: bad arguments");
+    const long total = (long)NC * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(shift_maxpool2_fwd_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y,
+                       NC, H, W, shift);
+    return sprk::check_launch("shift_maxpool2_fwd");
+}
+
+int sprk_shift_maxpool2_bwd(const float *gy, const float *x, float *gx, int NC, int H, int W, int shift, void *stream) {
+    SPRK_REQUIRE(gy && x && gx && NC > 0 && H >= 2 && W >= 2 && shift >= 0, "shift_maxpool2_bwd: bad arguments");
+    const long total = (long)NC * H * W;
+    hipLaunchKernelGGL(shift_maxpool2_bwd_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, gy,
+                       x, gx, NC, H, W, shift);
+    return sprk::check_launch("shift_maxpool2_bwd");
+}
+
+int sprk_rot4_stack_fwd(const float *x, float *y, int B, int C, int P, void *stream) {
+    SPRK_REQUIRE(x && y && B > 0 && C > 0 && P > 0, "rot4_stack_fwd: bad arguments");
+    hipLaunchKernelGGL(rot4_stack_fwd_kernel, dim3(sprk::ew_blocks(4L * B * C * P * P)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, B, C, P);
+    return sprk::check_launch("rot4_stack_fwd");
+}
+
+int sprk_rot4_stack_bwd(const float *gy, float *gx, int B, int C, int P, void *stream) {
+    SPRK_REQUIRE(gy && gx && B > 0 && C > 0 && P > 0, "rot4_stack_bwd: bad arguments");
+    hipLaunchKernelGGL(rot4_stack_bwd_kernel, dim3(sprk::ew_blocks((long)B * C * P * P)), dim3(256), 0,
+                       (hipStream_t)stream, gy, gx, B, C, P);
+    return sprk::check_launch("rot4_stack_bwd");
+}
+
+int sprk_unrot4_shift_concat_fwd(const float *d, float *f, int B, int C, int P, void *stream) {
+    SPRK_REQUIRE(d && f && B > 0 && C > 0 && P > 0, "unrot4_shift_concat_fwd: bad arguments");
+    hipLaunchKernelGGL(unrot4_fwd_kernel, dim3(sprk::ew_blocks(4L * B * C * P * P)), dim3(256), 0, (hipStream_t)stream,
+                       d, f, B, C, P);
+    return sprk::check_launch("unrot4_fwd");
+}
+
+int sprk_unrot4_shift_concat_bwd(const float *gf, float *gd, int B, int C, int P, void *stream) {
+    SPRK_REQUIRE(gf && gd && B > 0 && C > 0 && P > 0, "unrot4_shift_concat_bwd: bad arguments");
+    hipLaunchKernelGGL(unrot4_bwd_kernel, dim3(sprk::ew_blocks(4L * B * C * P * P)), dim3(256), 0, (hipStream_t)stream,
+                       gf, gd, B, C, P);
+    return sprk::check_launch("unrot4_bwd");
+}
+
+int sprk_reparam_fwd(const float *out_stats, const float *eps, float *z, int B, int HW, void *stream) {
+    SPRK_REQUIRE(out_stats && eps && z && B > 0 && HW > 0, "reparam_fwd: bad arguments");
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(sprk::ew_blocks((long)B * HW)), dim3(256), 0, (hipStream_t)stream,
+                       out_stats, eps, z, B, HW);
+    return sprk::check_launch("reparam_fwd");
+}
+
+int sprk_reparam_bwd(const float *gz, const float *out_stats, const float *eps, float *g_out_stats, int B, int HW,
+                     void *stream) {
+    SPRK_REQUIRE(gz && out_stats && eps && g_out_stats && B > 0 && HW > 0, "reparam_bwd: bad arguments");
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(sprk::ew_blocks((long)B * HW)), dim3(256), 0, (hipStream_t)stream, gz,
+                       out_stats, eps, g_out_stats, B, HW);
+    return sprk::check_launch("reparam_bwd");
+}
+
+int sprk_sigmoid_clamp_fwd(const float *x, float *p, long n, void *stream) {
+    SPRK_REQUIRE(x && p && n > 0, "sigmoid_clamp_fwd: bad arguments");
+    hipLaunchKernelGGL(sigmoid_clamp_fwd_kernel, dim3(sprk::ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, p, n);
+    return sprk::check_launch("sigmoid_clamp_fwd");
+}
+
+int sprk_sigmoid_clamp_bwd(const float *gp, const float *x, float *gx, long n, void *stream) {
+    SPRK_REQUIRE(gp && x && gx && n > 0, "sigmoid_clamp_bwd: bad arguments");
+    hipLaunchKernelGGL(sigmoid_clamp_bwd_kernel, dim3(sprk::ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, gp, x, gx,
+                       n);
+    return sprk::check_launch("sigmoid_clamp_bwd");
+}
+
+size_t sprk_ssdn_ws_bytes(int B, int HW) { return (size_t)B * ssdn_nblk(HW) * sizeof(float); }
+
+int sprk_ssdn_fwd(const float *x, const float *out_stats, const float *noise_std, float *loss, float *pme,
+                  float *model_std, int B, int HW, void *ws, size_t ws_bytes, void *stream) {
+    SPRK_REQUIRE(x && out_stats && noise_std && loss && B > 0 && HW > 0, "ssdn_fwd: bad arguments");
+    const int nblk = ssdn_nblk(HW);
+    if (!ws || ws_bytes < (size_t)B * nblk * sizeof(float)) {
+        sprk::set_error("ssdn_fwd: workspace too small");
+        return SPRK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ssdn_fwd_kernel, dim3(nblk, B), dim3(kSsdnBlk), 0, s, x, out_stats, noise_std, (float *)ws, pme,
+                       model_std, HW);
+    if (int rc = sprk::check_launch("ssdn_fwd")) return rc;
+    hipLaunchKernelGGL(ssdn_finish_kernel, dim3(sprk::cdiv(B, 64)), dim3(64), 0, s, (const float *)ws, loss, B, nblk,
+                       1.0f / (float)HW);
+    return sprk::check_launch("ssdn_finish");
+}
+
+int sprk_ssdn_bwd(const float *gloss, const float *x, const float *out_stats, const float *noise_std,
+                  float *g_out_stats, float *g_noise_std, int B, int HW, void *ws, size_t ws_bytes, void *stream) {
+    SPRK_REQUIRE(gloss && x && out_stats && noise_std && g_out_stats && g_noise_std && B > 0 && HW > 0,
+                 "ssdn_bwd: bad arguments");
+    const int nblk = ssdn_nblk(HW);
+    if (!ws || ws_bytes < (size_t)B * nblk * sizeof(float)) {
+        sprk::set_error("ssdn_bwd: workspace too small");
+        return SPRK_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ssdn_bwd_kernel, dim3(nblk, B), dim3(kSsdnBlk), 0, s, gloss, x, out_stats, noise_std,
+                       g_out_stats, (float *)ws, HW);
+    if (int rc = sprk::check_launch("ssdn_bwd")) return rc;
+    hipLaunchKernelGGL(ssdn_finish_kernel, dim3(sprk::cdiv(B, 64)), dim3(64), 0, s, (const float *)ws, g_noise_std, B,
+                       nblk, 1.0f);
+    return sprk::check_launch("ssdn_finish");
+}
+
+}  // extern "C"

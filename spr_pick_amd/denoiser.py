@@ -1,0 +1,234 @@
+"""``Denoiser``: the reference's pipeline object (spr_pick/denoiser_v2.py:36-870) on libsprk.so.
+
+Same constructor, ``models`` / ``_models`` dictionaries, ``run_pipeline`` / ``forward`` / ``fill`` /
+``unfill`` / ``state_dict`` / ``from_state_dict`` / ``config_name`` surface and the same output
+dictionary, for the configuration BASELINE.json runs: 1 channel, gaussian noise model,
+``--noise_value var`` (sigma network), modes "joint" (``_new_pipeline`` :253-589) and "denoise"
+(``_ssdn_pipeline`` :598-849).  Differences that are deliberate:
+
+  * the random draws the reference takes implicitly (eps of the reparameterisation, the flip axis)
+    can be passed in (``eps=``, ``eps_flip=``, ``flip_p=``) so runs can be replayed exactly;
+  * the PU loss never leaves the device: label counts come from the host copy of ``target`` and
+    the binomial table is cached per (N, tau) (reference: ``.item()`` + scipy every step);
+  * everything per-pixel is a fused HIP kernel (ops.py).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from scipy import stats
+
+from . import cfg as cfg_mod
+from . import ops
+from .datasets import DetectionDataset
+from .networks import DualNetworkShallow, JointNetwork
+from .params import ConfigValue, NoiseValue, Pipeline, PipelineOutput
+
+
+def _sigmoid(x):
+    """clamp(sigmoid(x), 1e-4, 1-1e-4) (denoiser_v2.py:32-34)."""
+    return ops.sigmoid_clamp(x)
+
+
+class PuLoss(nn.Module):
+    """BCE on labelled patches + slack * binomial generalised-expectation penalty on unlabelled
+    ones (utils/losses.py:303-349), evaluated with masks so that no device->host sync is needed."""
+
+    def __init__(self):
+        super().__init__()
+        self._tables = {}
+
+    def _log_binom(self, n, tau, device):
+        key = (n, float(tau), str(device))
+        if key not in self._tables:
+            t = stats.binom.logpmf(np.arange(0, n + 1), n, tau)
+            self._tables[key] = (torch.from_numpy(t).float().to(device),
+                                 torch.arange(0, n + 1, dtype=torch.float32, device=device))
+        return self._tables[key]
+
+    def forward(self, tau, p, y_host, slack=4.0):
+        p = p.reshape(-1)
+        yh = y_host.reshape(-1).float()
+        lab_h = yh >= 0
+        unl_h = yh == -1
+        n_lab, n_unl = int(lab_h.sum()), int(unl_h.sum())
+        dev = p.device
+        loss = 0
+        if n_lab > 0:
+            y = torch.where(lab_h, yh, torch.zeros_like(yh)).to(dev)
+            m = lab_h.float().to(dev)
+            bce = -(y * torch.log(p) + (1 - y) * torch.log(1 - p))
+            loss = (bce * m).sum() / n_lab
+        m = unl_h.float().to(dev)
+        q_mu = (p * m).sum()
+        q_var = (p * (1 - p) * m).sum()
+        log_binom, counts = self._log_binom(n_unl, tau, dev)
+        q = torch.softmax(-0.5 * (q_mu - counts) ** 2 / (q_var + 1e-7), dim=0)
+        return loss + slack * (-(log_binom * q).sum())
+
+
+class Denoiser(nn.Module):
+    MODEL = "denoiser_model"
+    SIGMA_ESTIMATOR = "sigma_estimation_model"
+    ESTIMATED_SIGMA = "estimated_sigma"
+    PROB_ESTIMATOR = "detector_model"
+
+    def __init__(self, cfg, device=None, mode=None):
+        super().__init__()
+        self.device = torch.device(device) if device else torch.device("cuda")
+        if self.device.type != "cuda":
+            raise RuntimeError("spr_pick_amd.Denoiser runs on the GPU only (device=%s); use the oracle/ "
+                               "restatement for CPU checks" % self.device)
+        self.cfg = cfg
+        self.mode = mode
+        self.models = nn.ModuleDict()
+        self._models = nn.ModuleDict()
+        self.init_networks()
+        self.l_params = nn.ParameterDict()
+        self.init_l_params()
+        self._pu = PuLoss()
+
+    def init_networks(self):
+        c = self.cfg
+        in_channels = c[ConfigValue.IMAGE_CHANNELS]
+        if in_channels != 1:
+            raise NotImplementedError("only IMAGE_CHANNELS == 1 (micrographs) is on the hot path")
+        self.add_model(Denoiser.MODEL, JointNetwork(in_channels=in_channels, out_channels=2,
+                                                    blindspot=c[ConfigValue.BLINDSPOT], detect=True))
+        if c[ConfigValue.PIPELINE] == Pipeline.SSDN and c[ConfigValue.NOISE_VALUE] == NoiseValue.UNKNOWN_VARIABLE:
+            self.add_model(Denoiser.SIGMA_ESTIMATOR, DualNetworkShallow(in_channels=in_channels, out_channels=1,
+                                                                        blindspot=False, detect=False))
+
+    def fill(self, stride=1):
+        return self.models[Denoiser.MODEL].fill(stride=stride)
+
+    def unfill(self):
+        return self.models[Denoiser.MODEL].unfill()
+
+    def init_l_params(self):
+        c = self.cfg
+        if c[ConfigValue.PIPELINE] == Pipeline.SSDN and c[ConfigValue.NOISE_VALUE] == NoiseValue.UNKNOWN_CONSTANT:
+            self.l_params[Denoiser.ESTIMATED_SIGMA] = nn.Parameter(torch.zeros((1, 1, 1, 1), device=self.device))
+
+    def get_model(self, model_id, parallelised=True):
+        return (self.models if parallelised else self._models)[model_id]
+
+    def add_model(self, model_id, model, parallelise=False):
+        if parallelise:
+            raise NotImplementedError("nn.DataParallel is never enabled by the reference (denoiser_v2.py:170); "
+                                      "multi-GPU here is one process per GPU (spr_pick_amd.distributed)")
+        self._models[model_id] = model
+        model.to(self.device)
+        self.models[model_id] = model
+
+    def forward(self, data):
+        outputs = self.run_pipeline([data])
+        return outputs[PipelineOutput.IMG_DENOISED]
+
+    def run_pipeline(self, data, alpha=0, tau=0, train=True, **kwargs):
+        if self.cfg[ConfigValue.PIPELINE] == Pipeline.SSDN and self.mode == "denoise":
+            return self._ssdn_pipeline(data, **kwargs)
+        if self.mode == "joint":
+            return self._new_pipeline(data, alpha, tau, train=train, **kwargs)
+        raise NotImplementedError("Unsupported processing pipeline")
+
+    # ------------------------------------------------------------------------------------------
+    def _noise_std(self, noisy_in):
+        c = self.cfg
+        nv = c[ConfigValue.NOISE_VALUE]
+        if nv == NoiseValue.UNKNOWN_CONSTANT:
+            est = self.l_params[Denoiser.ESTIMATED_SIGMA].expand(noisy_in.shape[0], 1, 1, 1)
+        elif nv == NoiseValue.UNKNOWN_VARIABLE:
+            est = self.models[Denoiser.SIGMA_ESTIMATOR](noisy_in)
+            est = torch.mean(est, dim=(2, 3), keepdim=True)
+        else:
+            raise NotImplementedError("NoiseValue.KNOWN is not reachable from the joint pipeline "
+                                      "(noise_params_in is undefined in the reference, denoiser_v2.py:406)")
+        return torch.nn.functional.softplus(est - 4.0) + 1e-3
+
+    def _check_style(self):
+        style = self.cfg[ConfigValue.NOISE_STYLE]
+        if style is None or not style.startswith("gauss"):
+            raise NotImplementedError("only the gaussian likelihood branch (--noise_style gauss*) is on the hot path")
+
+    def _new_pipeline(self, data, alpha, tau, train, eps=None, eps_flip=None, flip_p=None, **kwargs):
+        if not len(data) > 2:
+            return None  # as the reference: the joint pipeline needs the full batch list (denoiser_v2.py:261)
+        self._check_style()
+        inp, target = data[DetectionDataset.INPUT], data[DetectionDataset.TARGET]
+        hm = data[DetectionDataset.HM]
+        metadata = data[DetectionDataset.METADATA]
+        gt = metadata.get(DetectionDataset.Metadata.GT) if isinstance(metadata, dict) else None
+        target_host = target.detach().cpu() if torch.is_tensor(target) else torch.as_tensor(target)
+        inp = inp.to(self.device, dtype=torch.float32)
+        if torch.is_tensor(hm):
+            hm = hm.to(self.device)
+        model = self.models[Denoiser.MODEL]
+
+        net_out, hm_p = model(inp, eps=eps)
+        hm_p = _sigmoid(hm_p)
+        if train:
+            p = np.random.rand() if flip_p is None else flip_p
+            axis = -1 if p <= 0.5 else -2
+            _, hm_p_f = model(inp.flip(axis), eps=eps_flip)
+            hm_p_f = _sigmoid(hm_p_f.flip(axis))
+            pred_loss = self._pu(tau, hm_p, target_host)
+
+        mu_x = net_out[:, 0:1]
+        noise_std = self._noise_std(inp)
+        loss_out, pme_out, net_std_out = ops.ssdn_nll_pme(inp, net_out, noise_std)
+        if train:
+            consis_loss = torch.nn.functional.mse_loss(hm_p, hm_p_f)
+            final_loss = alpha * loss_out + (1 - alpha) * pred_loss + 0.1 * consis_loss
+        else:
+            final_loss, pred_loss, consis_loss = loss_out, 0, 0
+        return {
+            PipelineOutput.INPUTS: data,
+            PipelineOutput.IMG_MU: mu_x,
+            PipelineOutput.TARGET: hm,
+            PipelineOutput.AUG_LOSS: consis_loss,
+            PipelineOutput.LOSS: final_loss,
+            PipelineOutput.IMG_DENOISED: pme_out,
+            PipelineOutput.DETECT_LOSS: pred_loss,
+            PipelineOutput.DENOISE_LOSS: loss_out,
+            PipelineOutput.NOISE_STD_DEV: noise_std[:, 0],
+            PipelineOutput.MODEL_STD_DEV: net_std_out,
+            PipelineOutput.DETECT: hm_p,
+            PipelineOutput.GT: gt,
+        }
+
+    def _ssdn_pipeline(self, data, **kwargs):
+        self._check_style()
+        inp, target = data[DetectionDataset.INPUT], data[DetectionDataset.TARGET]
+        inp = inp.to(self.device, dtype=torch.float32)
+        if torch.is_tensor(target):
+            target = target.to(self.device)
+        # the reference calls the whole JointNetwork here too but only uses out_stats
+        res = self.models[Denoiser.MODEL].denoise_branch(inp)
+        net_out = res[0] if isinstance(res, tuple) else res
+        noise_std = self._noise_std(inp)
+        loss_out, pme_out, net_std_out = ops.ssdn_nll_pme(inp, net_out, noise_std)
+        return {
+            PipelineOutput.INPUTS: data,
+            PipelineOutput.IMG_MU: net_out[:, 0:1],
+            PipelineOutput.TARGET: target,
+            PipelineOutput.IMG_DENOISED: pme_out,
+            PipelineOutput.LOSS: loss_out,
+            PipelineOutput.NOISE_STD_DEV: noise_std[:, 0],
+            PipelineOutput.MODEL_STD_DEV: net_std_out,
+        }
+
+    # ------------------------------------------------------------------------------------------
+    def state_dict(self, params_only=False, **kw):
+        sd = super().state_dict(**kw)
+        if not params_only:
+            sd["cfg"] = self.cfg
+        return sd
+
+    @staticmethod
+    def from_state_dict(state_dict, mode, device=None):
+        den = Denoiser(state_dict["cfg"], device=device, mode=mode)
+        den.load_state_dict({k: v for k, v in state_dict.items() if k != "cfg"}, strict=False)
+        return den
+
+    def config_name(self):
+        return cfg_mod.config_name(self.cfg)

@@ -1,0 +1,350 @@
+"""torch autograd operators over the libsprk.so C ABI (include/sprk.h).
+
+Every operator here launches hand-written HIP kernels on torch's current stream through
+ctypes; PyTorch only provides device memory, the stream and the autograd tape.  There is no
+alternative implementation: CPU tensors or a missing library raise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ConvEpilogue, ConvGeom, check  # noqa: F401
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and (not t.is_cuda or t.dtype != torch.float32):
+            raise _lib.SprkError("spr_pick_amd ops need float32 tensors on the GPU (got %s on %s); "
+                                 "there is no CPU path" % (t.dtype, t.device))
+
+
+def _ws(nbytes, like):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+
+
+def conv_out_size(n, k, stride, dil, pad_lo, pad_hi):
+    return (n + pad_lo + pad_hi - dil * (k - 1) - 1) // stride + 1
+
+
+def make_geom(x, x2, w, up1, stride, dil, pad, out_hw=None):
+    """pad = (top, bottom, left, right) zero padding of the (virtual) conv input."""
+    N, C1 = x.shape[0], x.shape[1]
+    Hin, Win = (x.shape[2] * 2, x.shape[3] * 2) if up1 else (x.shape[2], x.shape[3])
+    C2 = 0 if x2 is None else x2.shape[1]
+    if x2 is not None and (x2.shape[0] != N or x2.shape[2] != Hin or x2.shape[3] != Win):
+        raise ValueError("conv2d: skip tensor %s does not match input %s" % (tuple(x2.shape), (N, C1, Hin, Win)))
+    Cout, Cin, KH, KW = w.shape
+    if Cin != C1 + C2:
+        raise ValueError("conv2d: weight expects %d input channels, got %d+%d" % (Cin, C1, C2))
+    pt, pb, pl, pr = pad
+    Hout = conv_out_size(Hin, KH, stride, dil, pt, pb)
+    Wout = conv_out_size(Win, KW, stride, dil, pl, pr)
+    if out_hw is not None:
+        Hout, Wout = out_hw
+    if Hout <= 0 or Wout <= 0:
+        raise ValueError("conv2d: input %dx%d too small for kernel %dx%d dil %d" % (Hin, Win, KH, KW, dil))
+    return ConvGeom(N, C1, C2, Hin, Win, 1 if up1 else 0, Cout, Hout, Wout, KH, KW, stride, dil, pt, pl)
+
+
+def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None, res=None, res_off=0):
+    """Raw forward launch (no autograd).  Returns y [N,Cout,Hout,Wout]."""
+    L = _lib.lib()
+    _need_gpu(x, x2, w, bias, scale, shift, res)
+    y = torch.empty((g.N, g.Cout, g.Hout, g.Wout), dtype=torch.float32, device=x.device)
+    ep = ConvEpilogue(_p(bias), _p(scale), _p(shift), _p(res),
+                      0 if res is None else res.shape[2], 0 if res is None else res.shape[3], res_off, act)
+    nb = L.sprk_conv2d_fwd_ws_bytes(ctypes.byref(g))
+    ws = _ws(nb, x)
+    check(L.sprk_conv2d_fwd(_p(x), _p(x2), _p(w), _p(y), ctypes.byref(g), ctypes.byref(ep), _p(ws), nb, _stream()),
+          "sprk_conv2d_fwd")
+    return y
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, x2, w, bias, up1, stride, dil, pad, act):
+        x = x.contiguous()
+        x2 = None if x2 is None else x2.contiguous()
+        w = w.contiguous()
+        g = make_geom(x, x2, w, up1, stride, dil, pad)
+        y = conv2d_forward(x, x2, w, g, bias=bias, act=act)
+        ctx.geom = g
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.lib()
+        x, x2, w, y = ctx.saved_tensors
+        g = ctx.geom
+        gy = gy.contiguous()
+        _need_gpu(gy)
+        gx = gx2 = gw = gb = None
+        need_b = ctx.has_bias and ctx.needs_input_grad[3]
+        # gradient w.r.t. the pre-activation output (+ bias gradient)
+        if ctx.act != ACT_NONE or need_b:
+            gpre = torch.empty_like(gy) if ctx.act != ACT_NONE else gy
+            if need_b:
+                gb = torch.empty(g.Cout, dtype=torch.float32, device=gy.device)
+            nb = L.sprk_act_bwd_ws_bytes(g.N, g.Cout, g.Hout * g.Wout)
+            ws = _ws(nb, gy)
+            check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre) if ctx.act != ACT_NONE else None, _p(gb), ctx.act,
+                                 g.N, g.Cout, g.Hout * g.Wout, _p(ws), nb, _stream()), "sprk_act_bwd")
+        else:
+            gpre = gy
+        if ctx.needs_input_grad[2]:
+            gw = torch.empty_like(w)
+            nb = L.sprk_conv2d_bwd_weight_ws_bytes(ctypes.byref(g))
+            ws = _ws(nb, gy)
+            check(L.sprk_conv2d_bwd_weight(_p(x), _p(x2), _p(gpre), _p(gw), ctypes.byref(g), _p(ws), nb, _stream()),
+                  "sprk_conv2d_bwd_weight")
+        need_x = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+        if need_x:
+            gin = torch.empty((g.N, g.C1 + g.C2, g.Hin, g.Win), dtype=torch.float32, device=gy.device)
+            nb = L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(g))
+            ws = _ws(nb, gy)
+            check(L.sprk_conv2d_bwd_data(_p(gpre), _p(w), _p(gin), ctypes.byref(g), _p(ws), nb, _stream()),
+                  "sprk_conv2d_bwd_data")
+            if g.C2 == 0 and not g.up1:
+                gx = gin
+            else:
+                gx = torch.empty_like(x)
+                gx2 = torch.empty_like(x2) if x2 is not None else None
+                check(L.sprk_concat_up_bwd(_p(gin), _p(gx), _p(gx2), g.N, g.C1, g.C2, g.Hin, g.Win, g.up1, _stream()),
+                      "sprk_concat_up_bwd")
+        return gx, gx2, gw, gb, None, None, None, None, None
+
+
+def conv2d(x, w, bias=None, x2=None, up1=False, stride=1, dil=1, pad=(0, 0, 0, 0), act=ACT_NONE):
+    """y = act(conv(cat(up2(x) if up1 else x, x2), w) + bias); pad = (top, bottom, left, right)."""
+    _need_gpu(x, x2, w, bias)
+    return _Conv2dFn.apply(x, x2, w, bias, bool(up1), int(stride), int(dil), tuple(int(p) for p in pad), int(act))
+
+
+# ---- U-Net plumbing -----------------------------------------------------------------------------
+class _ShiftMaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, shift):
+        x = x.contiguous()
+        _need_gpu(x)
+        N, C, H, W = x.shape
+        if H % 2 or W % 2:
+            raise ValueError("shift_maxpool2: odd spatial size %dx%d" % (H, W))
+        y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        check(_lib.lib().sprk_shift_maxpool2_fwd(_p(x), _p(y), N * C, H, W, shift, _stream()), "sprk_shift_maxpool2_fwd")
+        ctx.shift = shift
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        check(_lib.lib().sprk_shift_maxpool2_bwd(_p(gy), _p(x), _p(gx), N * C, H, W, ctx.shift, _stream()),
+              "sprk_shift_maxpool2_bwd")
+        return gx, None
+
+
+def shift_maxpool2(x, shift=1):
+    return _ShiftMaxPoolFn.apply(x, int(shift))
+
+
+class _Rot4Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _need_gpu(x)
+        B, C, H, W = x.shape
+        if H != W:
+            raise ValueError("rot4_stack needs square images, got %dx%d" % (H, W))
+        y = torch.empty((4 * B, C, H, W), dtype=x.dtype, device=x.device)
+        check(_lib.lib().sprk_rot4_stack_fwd(_p(x), _p(y), B, C, H, _stream()), "sprk_rot4_stack_fwd")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        B4, C, P, _ = gy.shape
+        gx = torch.empty((B4 // 4, C, P, P), dtype=gy.dtype, device=gy.device)
+        check(_lib.lib().sprk_rot4_stack_bwd(_p(gy), _p(gx), B4 // 4, C, P, _stream()), "sprk_rot4_stack_bwd")
+        return gx
+
+
+def rot4_stack(x):
+    return _Rot4Fn.apply(x)
+
+
+class _UnrotFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d):
+        d = d.contiguous()
+        _need_gpu(d)
+        B4, C, P, W = d.shape
+        if P != W or B4 % 4:
+            raise ValueError("unrot4_shift_concat: bad shape %s" % (tuple(d.shape),))
+        f = torch.empty((B4 // 4, 4 * C, P, P), dtype=d.dtype, device=d.device)
+        check(_lib.lib().sprk_unrot4_shift_concat_fwd(_p(d), _p(f), B4 // 4, C, P, _stream()), "sprk_unrot4_fwd")
+        return f
+
+    @staticmethod
+    def backward(ctx, gf):
+        gf = gf.contiguous()
+        B, C4, P, _ = gf.shape
+        gd = torch.empty((4 * B, C4 // 4, P, P), dtype=gf.dtype, device=gf.device)
+        check(_lib.lib().sprk_unrot4_shift_concat_bwd(_p(gf), _p(gd), B, C4 // 4, P, _stream()), "sprk_unrot4_bwd")
+        return gd
+
+
+def unrot4_shift_concat(d):
+    return _UnrotFn.apply(d)
+
+
+# ---- BatchNorm ------------------------------------------------------------------------------------
+class _BNTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        x = x.contiguous()
+        _need_gpu(x, gamma, beta)
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        check(_lib.lib().sprk_bn_train_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                           _p(mean), _p(invstd), N, C, H * W, momentum, eps, int(relu), _stream()),
+              "sprk_bn_train_fwd")
+        ctx.relu = relu
+        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, gamma, mean, invstd = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, C, H, W = x.shape
+        gx = torch.empty_like(x)
+        gg = torch.empty(C, dtype=torch.float32, device=x.device)
+        gb = torch.empty(C, dtype=torch.float32, device=x.device)
+        check(_lib.lib().sprk_bn_train_bwd(_p(gy), _p(x), _p(y), _p(gamma), _p(mean), _p(invstd), _p(gx), _p(gg), _p(gb),
+                                           N, C, H * W, int(ctx.relu), _stream()), "sprk_bn_train_bwd")
+        return gx, gg, gb, None, None, None, None, None
+
+
+def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=False):
+    return _BNTrainFn.apply(x, gamma, beta, running_mean, running_var, float(momentum), float(eps), bool(relu))
+
+
+def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, relu=False):
+    """Inference-only (no autograd)."""
+    x = x.contiguous()
+    _need_gpu(x)
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    check(_lib.lib().sprk_bn_eval_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                      N, C, H * W, float(eps), int(relu), _stream()), "sprk_bn_eval_fwd")
+    return y
+
+
+# ---- per-pixel pipeline maths -------------------------------------------------------------------
+class _ReparamFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out_stats, eps):
+        out_stats = out_stats.contiguous()
+        eps = eps.contiguous()
+        _need_gpu(out_stats, eps)
+        B, C, H, W = out_stats.shape
+        if C != 2:
+            raise ValueError("reparameterize expects out_stats with 2 channels")
+        z = torch.empty((B, 1, H, W), dtype=out_stats.dtype, device=out_stats.device)
+        check(_lib.lib().sprk_reparam_fwd(_p(out_stats), _p(eps), _p(z), B, H * W, _stream()), "sprk_reparam_fwd")
+        ctx.save_for_backward(out_stats, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        out_stats, eps = ctx.saved_tensors
+        gz = gz.contiguous()
+        B, _, H, W = out_stats.shape
+        go = torch.empty_like(out_stats)
+        check(_lib.lib().sprk_reparam_bwd(_p(gz), _p(out_stats), _p(eps), _p(go), B, H * W, _stream()), "sprk_reparam_bwd")
+        return go, None
+
+
+def reparameterize(out_stats, eps):
+    return _ReparamFn.apply(out_stats, eps)
+
+
+class _SigmoidClampFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        _need_gpu(x)
+        p = torch.empty_like(x)
+        check(_lib.lib().sprk_sigmoid_clamp_fwd(_p(x), _p(p), x.numel(), _stream()), "sprk_sigmoid_clamp_fwd")
+        ctx.save_for_backward(x)
+        return p
+
+    @staticmethod
+    def backward(ctx, gp):
+        (x,) = ctx.saved_tensors
+        gp = gp.contiguous()
+        gx = torch.empty_like(x)
+        check(_lib.lib().sprk_sigmoid_clamp_bwd(_p(gp), _p(x), _p(gx), x.numel(), _stream()), "sprk_sigmoid_clamp_bwd")
+        return gx
+
+
+def sigmoid_clamp(x):
+    return _SigmoidClampFn.apply(x)
+
+
+class _SsdnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, out_stats, noise_std):
+        x = x.contiguous()
+        out_stats = out_stats.contiguous()
+        ns = noise_std.reshape(-1).contiguous()
+        _need_gpu(x, out_stats, ns)
+        B, _, H, W = out_stats.shape
+        L = _lib.lib()
+        loss = torch.empty((B, 1), dtype=torch.float32, device=x.device)
+        pme = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
+        mstd = torch.empty((1, B, H, W), dtype=torch.float32, device=x.device)
+        nb = L.sprk_ssdn_ws_bytes(B, H * W)
+        ws = _ws(nb, x)
+        check(L.sprk_ssdn_fwd(_p(x), _p(out_stats), _p(ns), _p(loss), _p(pme), _p(mstd), B, H * W, _p(ws), nb, _stream()),
+              "sprk_ssdn_fwd")
+        ctx.save_for_backward(x, out_stats, ns)
+        ctx.ns_shape = noise_std.shape
+        ctx.mark_non_differentiable(pme, mstd)
+        return loss, pme, mstd
+
+    @staticmethod
+    def backward(ctx, gloss, _gpme, _gmstd):
+        x, out_stats, ns = ctx.saved_tensors
+        B, _, H, W = out_stats.shape
+        L = _lib.lib()
+        gl = gloss.reshape(-1).contiguous()
+        go = torch.empty_like(out_stats)
+        gns = torch.empty(B, dtype=torch.float32, device=x.device)
+        nb = L.sprk_ssdn_ws_bytes(B, H * W)
+        ws = _ws(nb, x)
+        check(L.sprk_ssdn_bwd(_p(gl), _p(x), _p(out_stats), _p(ns), _p(go), _p(gns), B, H * W, _p(ws), nb, _stream()),
+              "sprk_ssdn_bwd")
+        return None, go, gns.reshape(ctx.ns_shape)
+
+
+def ssdn_nll_pme(x, out_stats, noise_std):
+    """(loss [B,1] = per-image mean NLL, pme [B,1,H,W], model_std [1,B,H,W])."""
+    return _SsdnFn.apply(x, out_stats, noise_std)

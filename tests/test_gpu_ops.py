@@ -1,0 +1,266 @@
+"""GPU parity of every libsprk.so operator against a plain PyTorch fp32/fp64 CPU statement of the
+same op (floating-point kernels: tolerance stated per test), through the C ABI."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# fp32 MFMA is a k-ordered fp32 fma chain; the CPU reference below is evaluated in fp64, so the
+# budget is a few fp32 ulps of the accumulated magnitude: 2e-5 relative to the tensor's max |value|.
+REL = 2e-5
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def close(got, want, rel=REL, name=""):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = want.abs().max().item() + 1e-30
+    err = (got - want).abs()
+    worst = err.max().item()
+    if not worst <= rel * scale:
+        idx = np.unravel_index(int(err.argmax()), err.shape)
+        raise AssertionError("%s: max err %.3e (scale %.3e, rel %.2e) at %s got %.6g want %.6g; mismatches %d / %d" % (
+            name, worst, scale, worst / scale, idx, got[idx].item(), want[idx].item(),
+            int((err > rel * scale).sum()), err.numel()))
+
+
+def ref_conv(x, x2, w, b, up1, stride, dil, pad, act):
+    """fp64 CPU statement: cat(up(x), x2) -> zero pad (t,b,l,r) -> conv -> +bias -> act."""
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up1 else x
+    if x2 is not None:
+        xin = torch.cat((xin, x2), 1)
+    pt, pb, pl, pr = pad
+    xin = F.pad(xin, (pl, pr, pt, pb))
+    y = F.conv2d(xin, w, b, stride=stride, dilation=dil)
+    if act == 1:
+        y = F.leaky_relu(y, 0.1)
+    elif act == 2:
+        y = F.relu(y)
+    return y
+
+
+CONV_CASES = [
+    # name, N, C1, C2, H(in, after upsample), W, up1, Cout, K, stride, dil, pad(t,b,l,r), act, bias
+    ("enc1.0 shift 1->48 @64", 8, 1, 0, 64, 64, 0, 48, 3, 1, 1, (2, 0, 1, 1), 1, True),
+    ("enc1.2 shift 48->48 @64", 4, 48, 0, 64, 64, 0, 48, 3, 1, 1, (2, 0, 1, 1), 1, True),
+    ("enc2 shift 48->48 @32", 8, 48, 0, 32, 32, 0, 48, 3, 1, 1, (2, 0, 1, 1), 1, True),
+    ("enc4 shift 48->48 @8", 8, 48, 0, 8, 8, 0, 48, 3, 1, 1, (2, 0, 1, 1), 1, True),
+    ("enc6 shift 48->48 @2", 8, 48, 0, 2, 2, 0, 48, 3, 1, 1, (2, 0, 1, 1), 1, True),
+    ("dec5.0 shift up(48)+48->96 @4", 8, 48, 48, 4, 4, 1, 96, 3, 1, 1, (2, 0, 1, 1), 1, True),
+    ("dec4.0 shift up(96)+48->96 @8", 8, 96, 48, 8, 8, 1, 96, 3, 1, 1, (2, 0, 1, 1), 1, True),
+    ("dec3.2 shift 96->96 @16", 8, 96, 0, 16, 16, 0, 96, 3, 1, 1, (2, 0, 1, 1), 1, True),
+    ("dec1.0 shift up(96)+1->96 @64", 4, 96, 1, 64, 64, 1, 96, 3, 1, 1, (2, 0, 1, 1), 1, True),
+    ("dec1.2 shift 96->96 @64", 4, 96, 0, 64, 64, 0, 96, 3, 1, 1, (2, 0, 1, 1), 1, True),
+    ("sigma plain 48->48 @32", 4, 48, 0, 32, 32, 0, 48, 3, 1, 1, (1, 1, 1, 1), 1, True),
+    ("sigma plain up(96)+1->96 @64", 2, 96, 1, 64, 64, 1, 96, 3, 1, 1, (1, 1, 1, 1), 1, True),
+    ("head 1x1 384->384 @64", 2, 384, 0, 64, 64, 0, 384, 1, 1, 1, (0, 0, 0, 0), 1, True),
+    ("head 1x1 384->96 @64", 2, 384, 0, 64, 64, 0, 96, 1, 1, 1, (0, 0, 0, 0), 1, True),
+    ("head 1x1 96->2 @64", 2, 96, 0, 64, 64, 0, 2, 1, 1, 1, (0, 0, 0, 0), 0, True),
+    ("sigma 1x1 96->1 @64", 2, 96, 0, 64, 64, 0, 1, 1, 1, 1, (0, 0, 0, 0), 0, True),
+    ("det conv7 s2 1->32 @64", 4, 1, 0, 64, 64, 0, 32, 7, 2, 1, (0, 0, 0, 0), 0, False),
+    ("det 3x3 valid 32->32 @29", 4, 32, 0, 29, 29, 0, 32, 3, 1, 1, (0, 0, 0, 0), 0, False),
+    ("det 3x3 d2 32->32 @27", 4, 32, 0, 27, 27, 0, 32, 3, 1, 2, (0, 0, 0, 0), 0, False),
+    ("det 3x3 d2 s2 32->64 @21", 4, 32, 0, 21, 21, 0, 64, 3, 2, 2, (0, 0, 0, 0), 0, False),
+    ("det proj 1x1 s2 32->64 @17", 4, 32, 0, 17, 17, 0, 64, 1, 2, 1, (0, 0, 0, 0), 0, False),
+    ("det 3x3 64->128 @3", 4, 64, 0, 3, 3, 0, 128, 3, 1, 1, (0, 0, 0, 0), 2, False),
+    ("det cls 1x1 128->1 @1", 4, 128, 0, 1, 1, 0, 1, 1, 1, 1, (0, 0, 0, 0), 0, True),
+    ("filled conv7 pad31 1->32 @40x56", 1, 1, 0, 40, 56, 0, 32, 7, 1, 1, (31, 31, 31, 31), 0, False),
+    ("filled 3x3 d4 32->64 @60x44", 1, 32, 0, 60, 44, 0, 64, 3, 1, 4, (0, 0, 0, 0), 0, False),
+    ("filled 3x3 d8 64->64 @48x52", 1, 64, 0, 48, 52, 0, 64, 3, 1, 8, (0, 0, 0, 0), 0, False),
+    ("odd sizes 5->7 3x3 @13x9 pad(1,2,0,1)", 3, 5, 0, 13, 9, 0, 7, 3, 1, 1, (1, 2, 0, 1), 1, True),
+]
+
+
+@pytest.mark.parametrize("naive", [0, 1], ids=["mfma", "direct"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d_fwd_bwd(case, naive):
+    from spr_pick_amd import _lib, ops
+    name, N, C1, C2, H, W, up1, Cout, K, stride, dil, pad, act, has_b = case
+    g = torch.Generator().manual_seed(abs(hash(name)) % 10000)
+    h1, w1 = (H // 2, W // 2) if up1 else (H, W)
+    x = torch.randn(N, C1, h1, w1, generator=g)
+    x2 = torch.randn(N, C2, H, W, generator=g) if C2 else None
+    w = torch.randn(Cout, C1 + C2, K, K, generator=g) / np.sqrt((C1 + C2) * K * K)
+    b = torch.randn(Cout, generator=g) * 0.1 if has_b else None
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
+    yr = ref_conv(leaves[0], leaves[1], leaves[2], leaves[3], up1, stride, dil, pad, act)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+
+    d = dev()
+    L = _lib.lib()
+    L.sprk_set_naive(naive)
+    try:
+        dl = [t.to(d).requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
+        y = ops.conv2d(dl[0], dl[2], dl[3], x2=dl[1], up1=bool(up1), stride=stride, dil=dil, pad=pad, act=act)
+        close(y, yr, name=name + " y")
+        y.backward(gy.to(d))
+        torch.cuda.synchronize()
+    finally:
+        L.sprk_set_naive(0)
+    # gradients sum over up to N*H*W terms: budget relative to the gradient's own scale
+    close(dl[0].grad, leaves[0].grad, rel=5e-5, name=name + " gx")
+    if x2 is not None:
+        close(dl[1].grad, leaves[1].grad, rel=5e-5, name=name + " gx2")
+    close(dl[2].grad, leaves[2].grad, rel=5e-5, name=name + " gw")
+    if b is not None:
+        close(dl[3].grad, leaves[3].grad, rel=5e-5, name=name + " gb")
+
+
+def test_conv_epilogue_residual_affine():
+    """Inference epilogue: relu((conv + centre-crop(res)) * scale + shift)."""
+    from spr_pick_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 30, 26, generator=g)
+    w = torch.randn(32, 32, 3, 3, generator=g) / 17
+    res = torch.randn(2, 32, 34, 30, generator=g)
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+    want = F.relu((F.conv2d(x.double(), w.double(), dilation=4) + res.double()[:, :, 6:-6, 6:-6])
+                  * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+    d = dev()
+    xd, wd = x.to(d), w.to(d)
+    geom = ops.make_geom(xd, None, wd, False, 1, 4, (0, 0, 0, 0))
+    y = ops.conv2d_forward(xd, None, wd, geom, act=ops.ACT_RELU, scale=scale.to(d), shift=shift.to(d),
+                           res=res.to(d), res_off=6)
+    close(y, want, name="epilogue")
+
+
+@pytest.mark.parametrize("shift", [1, 0])
+@pytest.mark.parametrize("shape", [(3, 5, 64, 64), (2, 48, 8, 8), (4, 3, 2, 2), (1, 2, 6, 10)])
+def test_shift_maxpool(shape, shift):
+    from spr_pick_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(shape, generator=g)
+    xr = x.double().requires_grad_(True)
+    xs = F.pad(xr, (0, 0, shift, 0))[:, :, : shape[2]] if shift else xr
+    yr = F.max_pool2d(xs, 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    xd = x.to(dev()).requires_grad_(True)
+    y = ops.shift_maxpool2(xd, shift)
+    assert torch.equal(y.cpu(), yr.float())
+    y.backward(gy.to(dev()))
+    assert torch.equal(xd.grad.cpu(), xr.grad.float())
+
+
+@pytest.mark.parametrize("B,C,P", [(2, 1, 64), (3, 2, 8), (1, 4, 2), (2, 3, 96)])
+def test_rot4_and_unrot4(B, C, P):
+    from oracle import networks
+    from spr_pick_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, C, P, P, generator=g)
+    xr = x.clone().requires_grad_(True)
+    yr = torch.cat([networks.rot90cw(xr, a) for a in (0, 90, 180, 270)], 0)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xd = x.to(dev()).requires_grad_(True)
+    y = ops.rot4_stack(xd)
+    assert torch.equal(y.cpu(), yr.detach())
+    y.backward(gy.to(dev()))
+    close(xd.grad, xr.grad, rel=1e-6, name="rot4 grad")
+
+    dd = torch.randn(4 * B, C, P, P, generator=g)
+    dr = dd.clone().requires_grad_(True)
+    s = networks.shift_down(dr, 1)
+    fr = torch.cat([networks.rot90cw(q, a) for q, a in zip(torch.chunk(s, 4, 0), (0, 270, 180, 90))], 1)
+    gf = torch.randn(fr.shape, generator=g)
+    fr.backward(gf)
+    d2 = dd.to(dev()).requires_grad_(True)
+    f = ops.unrot4_shift_concat(d2)
+    assert torch.equal(f.cpu(), fr.detach())
+    f.backward(gf.to(dev()))
+    assert torch.equal(d2.grad.cpu(), dr.grad)
+
+
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("shape", [(4, 32, 29, 29), (8, 1, 64, 64), (4, 128, 1, 1), (3, 64, 9, 9)])
+def test_batch_norm(shape, relu):
+    from spr_pick_amd import ops
+    g = torch.Generator().manual_seed(3)
+    C = shape[1]
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    rm_r, rv_r = rm.double().clone(), rv.double().clone()
+    yr = F.batch_norm(xr, rm_r, rv_r, gr, br, True, 0.1, 1e-5)
+    if relu:
+        yr = F.relu(yr)
+    gy = torch.randn(shape, generator=g)
+    yr.backward(gy.double())
+    d = dev()
+    xd, gd, bd = (t.to(d).requires_grad_(True) for t in (x, gamma, beta))
+    rm_d, rv_d = rm.to(d), rv.to(d)
+    y = ops.batch_norm_train(xd, gd, bd, rm_d, rv_d, 0.1, 1e-5, relu)
+    close(y, yr, rel=1e-5, name="bn y")
+    y.backward(gy.to(d))
+    close(rm_d, rm_r, rel=1e-5, name="running_mean")
+    close(rv_d, rv_r, rel=1e-5, name="running_var")
+    close(xd.grad, xr.grad, rel=1e-4, name="bn gx")
+    close(gd.grad, gr.grad, rel=1e-4, name="bn ggamma")
+    close(bd.grad, br.grad, rel=1e-4, name="bn gbeta")
+    ye = ops.batch_norm_eval(x.to(d), gamma.to(d), beta.to(d), rm.to(d), rv.to(d), 1e-5, relu)
+    want = F.batch_norm(x.double(), rm.double(), rv.double(), gamma.double(), beta.double(), False, 0.1, 1e-5)
+    close(ye, F.relu(want) if relu else want, rel=1e-5, name="bn eval")
+
+
+def test_reparam_sigmoid_ssdn():
+    from oracle import pipeline
+    from spr_pick_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, H, W = 3, 64, 64
+    o = torch.randn(B, 2, H, W, generator=g)
+    eps = torch.randn(B, 1, H, W, generator=g)
+    x = torch.rand(B, 1, H, W, generator=g)
+    ns = torch.rand(B, 1, 1, 1, generator=g) * 0.3 + 0.05
+    d = dev()
+    # reparameterize
+    orr = o.double().requires_grad_(True)
+    zr = orr[:, 0:1] + eps.double() * orr[:, 1:2] ** 2
+    gz = torch.randn(zr.shape, generator=g)
+    zr.backward(gz.double())
+    od = o.to(d).requires_grad_(True)
+    z = ops.reparameterize(od, eps.to(d))
+    close(z, zr, rel=1e-6, name="z")
+    z.backward(gz.to(d))
+    close(od.grad, orr.grad, rel=1e-6, name="reparam grad")
+    # sigmoid clamp (large logits exercise both clamp sides)
+    lg = torch.randn(1000, generator=g) * 8
+    lr_ = lg.double().requires_grad_(True)
+    pr = torch.clamp(torch.sigmoid(lr_), 1e-4, 1 - 1e-4)
+    gp = torch.randn(1000, generator=g)
+    pr.backward(gp.double())
+    ld = lg.to(d).requires_grad_(True)
+    p = ops.sigmoid_clamp(ld)
+    close(p, pr, rel=1e-6, name="sigmoid")
+    p.backward(gp.to(d))
+    close(ld.grad, lr_.grad, rel=1e-5, name="sigmoid grad")
+    # ssdn
+    orr = o.double().requires_grad_(True)
+    nsr = ns.double().requires_grad_(True)
+    nll, pme, sx = pipeline.ssdn_terms(x.double(), orr[:, 0:1], orr[:, 1:2], nsr)
+    lossr = nll.reshape(B, -1).mean(1, keepdim=True)
+    gl = torch.randn(B, 1, generator=g)
+    lossr.backward(gl.double())
+    od = o.to(d).requires_grad_(True)
+    nsd = ns.to(d).requires_grad_(True)
+    loss, pm, ms = ops.ssdn_nll_pme(x.to(d), od, nsd)
+    close(loss, lossr, rel=2e-6, name="ssdn loss")
+    close(pm, pme, rel=2e-6, name="pme")
+    close(ms, (sx ** 0.5)[:, 0].unsqueeze(0), rel=2e-6, name="model std")
+    loss.backward(gl.to(d))
+    close(od.grad, orr.grad, rel=1e-5, name="ssdn g_out")
+    close(nsd.grad, nsr.grad, rel=1e-5, name="ssdn g_noise")
+
+
+def test_cpu_tensors_are_refused():
+    from spr_pick_amd import _lib, ops
+    with pytest.raises(_lib.SprkError):
+        ops.conv2d(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 3, 3))

@@ -1,0 +1,263 @@
+"""GPU parity of the HIP-backed networks / Denoiser against the oracle and the golden vectors
+generated from the reference (tests/golden), plus NMS coordinate parity (bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import check_probe, golden
+
+pytestmark = pytest.mark.gpu
+
+# End-to-end fp32 tolerance.  ~30 chained convolutions, each a differently-ordered fp32 sum than
+# the CPU reference: 1e-4 relative to each tensor's max |value| (observed ~1e-5).
+REL = 1e-4
+
+
+def close(got, want, rel=REL, name=""):
+    got = np.asarray(got.detach().cpu() if torch.is_tensor(got) else got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = np.abs(want).max() + 1e-30
+    worst = np.abs(got - want).max()
+    assert worst <= rel * scale, "%s: max err %.3e vs scale %.3e (rel %.2e)" % (name, worst, scale, worst / scale)
+
+
+def make_cfg():
+    from spr_pick_amd import cfg, params
+    c = cfg.base()
+    c[params.ConfigValue.ALGORITHM] = params.NoiseAlgorithm.SELFSUPERVISED_DENOISING
+    c[params.ConfigValue.NOISE_STYLE] = "gaussian"
+    c[params.ConfigValue.NOISE_VALUE] = params.NoiseValue.UNKNOWN_VARIABLE
+    c[params.ConfigValue.NMS] = 18
+    return cfg.infer(c, model_only=True)
+
+
+@pytest.fixture()
+def denoiser(oracle_state):
+    from spr_pick_amd import Denoiser
+    den = Denoiser(make_cfg(), device="cuda:0", mode="joint")
+    sd = {"models." + k: v for k, v in oracle_state.items()}
+    missing, unexpected = den.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith("_models.") for m in missing)
+    return den
+
+
+def test_state_dict_layout_matches_reference(denoiser):
+    import json, os
+    from conftest import GOLDEN
+    layout = json.load(open(os.path.join(GOLDEN, "state_layout.json")))
+    ours = denoiser.state_dict()
+    assert set(ours) == set(layout)
+    for k, v in ours.items():
+        if k != "cfg":
+            assert list(v.shape) == layout[k], k
+
+
+def test_unet_forward_and_blindspot(denoiser):
+    g = golden("unet_fwd.npz")
+    net = denoiser.models["denoiser_model"].denoise_branch
+    x = torch.from_numpy(g["x"]).cuda()
+    with torch.no_grad():
+        out, _ = net(x)
+        close(out, g["out_stats"], name="out_stats")
+        x2 = x.clone()
+        x2[0, 0, 20, 37] += 0.25
+        out2, _ = net(x2)
+    # blind-spot property, bit-exact: the perturbed pixel's own output cannot move
+    assert torch.equal(out[0, :, 20, 37], out2[0, :, 20, 37])
+    assert not torch.equal(out[0], out2[0])
+
+
+def test_sigma_net_and_detector_modes(denoiser):
+    g = golden("parts.npz")
+    jn = denoiser.models["denoiser_model"]
+    sg = denoiser.models["sigma_estimation_model"]
+    with torch.no_grad():
+        close(sg(torch.from_numpy(g["x"]).cuda()), g["sigma_out"], name="sigma")
+        z, zf = torch.from_numpy(g["z"]).cuda(), torch.from_numpy(g["zf"]).cuda()
+        det = jn.detector
+        det.eval(); det.unfill()
+        close(det(z), g["det_eval_unfilled"], name="det eval unfilled")
+        assert det.fill() == 4
+        close(det(zf), g["det_eval_filled"], name="det eval filled")
+        close(det(z[:1]), g["det_eval_filled64"], name="det eval filled 64")
+        det.unfill()
+    det.train()
+    out = det(z)
+    close(out, g["det_train_unfilled"], name="det train")
+    sd = det.state_dict()
+    for k in g.files:
+        if k.startswith("bn_after/"):
+            name = k[len("bn_after/"):]
+            close(sd[name].float(), g[k].astype(np.float64), rel=1e-5, name=name)
+
+
+@pytest.mark.parametrize("tag", ["w", "h"])
+def test_joint_train_step_matches_reference(denoiser, tag):
+    from spr_pick_amd import DetectionDataset
+    from spr_pick_amd.params import PipelineOutput as P
+    g = golden("joint_train_%s.npz" % tag)
+    denoiser.train(); denoiser.unfill()
+    data = DetectionDataset.make_batch(torch.from_numpy(g["inp"]), torch.from_numpy(g["target"]))
+    o = denoiser.run_pipeline(data, float(g["alpha"]), float(g["tau"]), train=True,
+                              eps=torch.from_numpy(g["eps"]).cuda(), eps_flip=torch.from_numpy(g["eps_flip"]).cuda(),
+                              flip_p=float(g["flip_p"]))
+    torch.mean(o[P.LOSS]).backward()
+    for key in ("LOSS", "DENOISE_LOSS", "DETECT", "IMG_MU", "IMG_DENOISED", "NOISE_STD_DEV", "MODEL_STD_DEV"):
+        close(o[getattr(P, key)], g[key], name=key)
+    close(o[P.DETECT_LOSS].reshape(()), g["DETECT_LOSS"], name="DETECT_LOSS")
+    close(o[P.AUG_LOSS].reshape(()), g["AUG_LOSS"], rel=1e-3, name="AUG_LOSS")
+    nograd = set(g["nograd"].tolist())
+    for name, p in denoiser.models.named_parameters():
+        if name in nograd:
+            assert p.grad is None, name
+        else:
+            assert p.grad is not None, name
+            # gradients: 2e-3 of each tensor's max |g| (long fp32 reductions over 4*B*64*64 pixels)
+            check_probe(g, "grad/" + name, p.grad, 2e-3, 0.0)
+    sd = denoiser.models["denoiser_model"].detector.state_dict()
+    for k in g.files:
+        if k.startswith("bn_after/"):
+            name = k[len("bn_after/"):]
+            close(sd[name].float(), g[k].astype(np.float64), rel=1e-4, name=name)
+
+
+def test_joint_eval_and_picks(denoiser, oracle_state):
+    from oracle import nms, pipeline
+    from spr_pick_amd import DetectionDataset, non_maximum_suppression
+    from spr_pick_amd.params import PipelineOutput as P
+    g = golden("joint_eval.npz")
+    denoiser.eval(); denoiser.fill()
+    with torch.no_grad():
+        o = denoiser.run_pipeline(DetectionDataset.make_batch(torch.from_numpy(g["inp"]), torch.zeros(1, 1)),
+                                  train=False, eps=torch.from_numpy(g["eps"]).cuda())
+    denoiser.unfill()
+    for key in ("LOSS", "DETECT", "IMG_MU", "IMG_DENOISED", "NOISE_STD_DEV", "MODEL_STD_DEV"):
+        close(o[getattr(P, key)], g[key], name=key)
+    # coordinate parity, bit-exact: (1) HIP NMS on the reference's score map == reference picks
+    for r in (18, 5):
+        s, c = non_maximum_suppression(g["DETECT"][0, 0], r, set(), 0.02)
+        assert np.array_equal(c, g["nms%d_coords" % r]) and np.array_equal(s, g["nms%d_scores" % r])
+    # (2) end to end: HIP scores -> HIP NMS == oracle NMS on the same HIP scores
+    score = o[P.DETECT][0, 0]
+    s, c = non_maximum_suppression(score, 18, set(), 0.02)
+    s2, c2 = nms.nms_c(score.cpu().numpy(), 18, 0.02)
+    assert np.array_equal(c, c2) and np.array_equal(s, s2)
+
+
+def test_ssdn_pipeline(oracle_state):
+    from spr_pick_amd import Denoiser, DetectionDataset
+    from spr_pick_amd.params import PipelineOutput as P
+    g = golden("ssdn_eval.npz")
+    den = Denoiser(make_cfg(), device="cuda:0", mode="denoise")
+    den.load_state_dict({"models." + k: v for k, v in oracle_state.items()}, strict=False)
+    den.eval()
+    with torch.no_grad():
+        o = den.run_pipeline(DetectionDataset.make_batch(torch.from_numpy(g["inp"]), torch.zeros(2, 1)))
+    for key in ("LOSS", "IMG_MU", "IMG_DENOISED", "NOISE_STD_DEV", "MODEL_STD_DEV"):
+        close(o[getattr(P, key)], g[key], name=key)
+
+
+def nms_case_names():
+    g = golden("nms_cases.npz")
+    return sorted({k.split("/")[0] for k in g.files})
+
+
+@pytest.mark.parametrize("name", nms_case_names())
+def test_nms_golden_cases(name):
+    from spr_pick_amd import non_maximum_suppression
+    g = golden("nms_cases.npz")
+    s, c = non_maximum_suppression(g[name + "/x"], int(g[name + "/r"]), set(), float(g[name + "/thr"]))
+    assert c.dtype == np.int32 and s.dtype == np.float32 and c.shape == (len(s), 2)
+    assert np.array_equal(c, g[name + "/coords"].reshape(-1, 2)), name
+    assert np.array_equal(s, g[name + "/scores"]), name
+
+
+@pytest.mark.parametrize("shape,r,thr,kind", [
+    ((512, 512), 18, 0.02, "rand"), ((300, 700), 7, 0.5, "rand"), ((1024, 1024), 18, 0.02, "blobs"),
+    ((257, 129), 40, 0.1, "rand"), ((128, 128), 3, 0.02, "ties"), ((400, 400), 18, 0.02, "ramp"),
+])
+def test_nms_vs_oracle_large(shape, r, thr, kind):
+    """Random / peaky / tied / monotone-ramp maps (long dependency chains) against the C oracle."""
+    from oracle import nms
+    from spr_pick_amd import non_maximum_suppression
+    rng = np.random.default_rng(7)
+    H, W = shape
+    if kind == "rand":
+        x = rng.random(shape, dtype=np.float32)
+    elif kind == "ties":
+        x = rng.integers(0, 6, size=shape).astype(np.float32) / 5.0
+    elif kind == "ramp":
+        yy, xx = np.mgrid[0:H, 0:W]
+        x = ((yy * 3 + xx * 2) / (5.0 * max(H, W))).astype(np.float32)
+    else:
+        yy, xx = np.mgrid[0:H, 0:W]
+        x = rng.random(shape) * 0.015
+        for _ in range(300):
+            cy, cx, a = rng.integers(0, H), rng.integers(0, W), rng.random() * 0.8 + 0.1
+            x += a * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / 32.0)
+        x = np.clip(x, 0, 0.9999).astype(np.float32)
+    s, c = non_maximum_suppression(x, r, set(), thr)
+    s2, c2 = nms.nms_c(x, r, thr)
+    assert len(s) == len(s2)
+    assert np.array_equal(c, c2) and np.array_equal(s, s2)
+
+
+def test_nms_full_size_properties():
+    """4096x4096 (BASELINE config 3 size): size-independent properties instead of the oracle."""
+    from spr_pick_amd import nms_device
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.rand((4096, 4096), generator=g, device="cuda") ** 8
+    r, thr = 18, 0.02
+    s, c = nms_device(x, r, thr)
+    s, c = s.cpu().numpy(), c.cpu().numpy().astype(np.int64)
+    assert len(s) > 1000 and np.all(s > thr)
+    assert np.all(np.diff(s) <= 0)                                   # sorted by descending score
+    assert np.array_equal(x.cpu().numpy()[c[:, 1], c[:, 0]], s)      # scores are the map's values
+    # picks are pairwise farther than r apart (checked on a grid hash)
+    cell = {}
+    for i, (px, py) in enumerate(c):
+        cell.setdefault((px // 19, py // 19), []).append(i)
+    for (gx, gy), idx in cell.items():
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for j in cell.get((gx + dx, gy + dy), []):
+                    for i in idx:
+                        if i < j:
+                            d2 = (c[i, 0] - c[j, 0]) ** 2 + (c[i, 1] - c[j, 1]) ** 2
+                            assert d2 > r * r
+    # idempotence: suppressing the picked-only map returns the same picks
+    y = torch.zeros_like(x)
+    y[torch.from_numpy(c[:, 1]).cuda(), torch.from_numpy(c[:, 0]).cuda()] = torch.from_numpy(s).cuda()
+    s3, c3 = nms_device(y, r, thr)
+    assert np.array_equal(c3.cpu().numpy(), c) and np.array_equal(s3.cpu().numpy(), s)
+
+
+def test_training_reduces_loss_and_is_deterministic(oracle_state):
+    """Three optimiser steps on a fixed batch: finite, decreasing loss, and two identical runs
+    produce bit-identical parameters (all reductions are order-fixed)."""
+    from spr_pick_amd import Denoiser, DetectionDataset
+    from spr_pick_amd.params import PipelineOutput as P
+    g = golden("joint_train_w.npz")
+
+    def run():
+        den = Denoiser(make_cfg(), device="cuda:0", mode="joint")
+        den.load_state_dict({"models." + k: v for k, v in oracle_state.items()}, strict=False)
+        den.train()
+        opt = torch.optim.Adam([p for p in den.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99))
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            o = den.run_pipeline(DetectionDataset.make_batch(torch.from_numpy(g["inp"]), torch.from_numpy(g["target"])),
+                                 0.75, 0.01, train=True, eps=torch.from_numpy(g["eps"]).cuda(),
+                                 eps_flip=torch.from_numpy(g["eps_flip"]).cuda(), flip_p=0.3)
+            loss = torch.mean(o[P.LOSS])
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        return losses, torch.cat([p.detach().reshape(-1) for p in den.models.parameters()])
+
+    l1, p1 = run()
+    l2, p2 = run()
+    assert all(np.isfinite(l1)) and l1[-1] < l1[0]
+    assert l1 == l2 and torch.equal(p1, p2)
