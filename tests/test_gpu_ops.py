@@ -89,18 +89,26 @@ def test_conv2d_fwd_bwd(case, naive):
     x2 = torch.randn(N, C2, H, W, generator=g) if C2 else None
     w = torch.randn(Cout, C1 + C2, K, K, generator=g) / np.sqrt((C1 + C2) * K * K)
     b = torch.randn(Cout, generator=g) * 0.1 if has_b else None
-    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
-    yr = ref_conv(leaves[0], leaves[1], leaves[2], leaves[3], up1, stride, dil, pad, act)
-    gy = torch.randn(yr.shape, generator=g)
-    yr.backward(gy.double())
-
     d = dev()
     L = _lib.lib()
     L.sprk_set_naive(naive)
     try:
         dl = [t.to(d).requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
         y = ops.conv2d(dl[0], dl[2], dl[3], x2=dl[1], up1=bool(up1), stride=stride, dil=dil, pad=pad, act=act)
-        close(y, yr, name=name + " y")
+        # fp64 CPU reference.  The backward of (Leaky)ReLU depends on the SIGN of the pre-activation;
+        # an fp32 result within rounding of zero may legitimately land on the other side than the
+        # fp64 one, so the reference backward uses the sign pattern of the GPU output.
+        leaves = [t.double().requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
+        pre = ref_conv(leaves[0], leaves[1], leaves[2], leaves[3], up1, stride, dil, pad, 0)
+        yr_true = ref_conv(leaves[0], leaves[1], leaves[2], leaves[3], up1, stride, dil, pad, act)
+        close(y, yr_true, name=name + " y")
+        if act:
+            pos = (y.detach().cpu() > 0)
+            yr = torch.where(pos, pre, pre * (0.1 if act == 1 else 0.0))
+        else:
+            yr = pre
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy.double())
         y.backward(gy.to(d))
         torch.cuda.synchronize()
     finally:
