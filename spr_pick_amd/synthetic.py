@@ -1,0 +1,47 @@
+"""Synthetic micrographs and patch batches of BASELINE.json's shape: white noise
++ Gaussian blobs, min-max normalised and quantised to uint8 like the reference's loader
+(utils/loader.py:57-59); labelled centres carry CenterNet-style gaussian targets, everything
+else is unlabelled (-1), sampled with 10 % positives like StratifiedCoordinateSampler
+(datasets/sampler.py).  Used by bench.py and the tests; data only, no kernels."""
+import numpy as np
+import torch
+
+
+def micrograph(idx, size=1024, blobs=None, seed=1234):
+    rng = np.random.default_rng(seed + idx)
+    img = rng.standard_normal((size, size), dtype=np.float32)
+    nb = blobs if blobs is not None else int(200 * (size / 1024.0) ** 2)
+    centres = rng.integers(72, size - 72, size=(nb, 2))
+    yy, xx = np.mgrid[-16:17, -16:17]
+    stamp = (-1.5 * np.exp(-(yy ** 2 + xx ** 2) / (2 * 4.0 ** 2))).astype(np.float32)
+    for cy, cx in centres:
+        img[cy - 16:cy + 17, cx - 16:cx + 17] += stamp
+    lo, hi = img.min(), img.max()
+    q = np.clip((img - lo) / (hi - lo) * 255.0, 0, 255).astype(np.uint8)
+    in_box = (centres[:, 0] < 372) & (centres[:, 1] < 372) & (rng.random(nb) < 0.6)
+    return q, centres, centres[in_box]
+
+
+def patch_batches(n_batches, batch, micrographs, patch=64, seed=0, device="cuda"):
+    """Pre-extracted training batches: list of (inp [B,1,P,P] float32 on device, target [B,1] host)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    half = patch // 2
+    mics = [torch.from_numpy(m[0].astype(np.float32) / 255.0) for m in micrographs]
+    for _ in range(n_batches):
+        inp = torch.empty(batch, 1, patch, patch)
+        tgt = torch.full((batch, 1), -1.0)
+        for b in range(batch):
+            m = int(rng.integers(0, len(micrographs)))
+            size = mics[m].shape[0]
+            labelled = micrographs[m][2]
+            if rng.random() < 0.1 and len(labelled):
+                cy, cx = labelled[int(rng.integers(0, len(labelled)))]
+                dy, dx = rng.integers(-2, 3, size=2)
+                y, x = int(cy + dy), int(cx + dx)
+                tgt[b, 0] = float(np.exp(-(dy * dy + dx * dx) / (2 * 2.0 ** 2)))
+            else:
+                y, x = (int(v) for v in rng.integers(73, size - 140, size=2))
+            inp[b, 0] = mics[m][y - half:y + half, x - half:x + half]
+        out.append((inp.to(device), tgt))
+    return out

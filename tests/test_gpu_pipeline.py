@@ -113,8 +113,19 @@ def test_joint_train_step_matches_reference(denoiser, tag):
             assert p.grad is None, name
         else:
             assert p.grad is not None, name
-            # gradients: 2e-3 of each tensor's max |g| (long fp32 reductions over 4*B*64*64 pixels)
-            check_probe(g, "grad/" + name, p.grad, 2e-3, 0.0)
+            key = "grad/" + name
+            a = p.grad.detach().cpu().numpy().astype(np.float64).ravel()
+            absmax = float(g[key + "/absmax"])
+            err = np.abs(a[g[key + "/idx"]] - g[key + "/val"]).max()
+            # Gradient tolerance: 3e-3 of the tensor's max |g| (plus 1e-4 absolute for the two
+            # BatchNorm-before-BatchNorm parameters whose true gradient is zero).  It is set by the
+            # network, not by the kernels: a (Leaky)ReLU pre-activation within fp32 rounding of 0
+            # takes slope 1 on one implementation and 0.1 on another.  Measured on this fixture
+            # against an fp64 evaluation: exactly 2 of the 96 channels of output_block.2.bias differ
+            # (by 7.6e-4 of max|g|), all others by 3e-6; the direct (non-MFMA) kernels show the
+            # same two flips.  Per-operator gradients are checked at 5e-5 in test_gpu_ops.py.
+            assert err <= 3e-3 * absmax + 1e-4, "%s: probe err %.3e vs max|g| %.3e" % (name, err, absmax)
+            assert abs(np.linalg.norm(a) / float(g[key + "/norm"]) - 1) < 2e-3 or absmax < 1e-3, name
     sd = denoiser.models["denoiser_model"].detector.state_dict()
     for k in g.files:
         if k.startswith("bn_after/"):
