@@ -42,7 +42,9 @@ def cpu_baseline(micrographs, seconds):
     configs[0]: batch 4, same synthetic patches; a bounded sample of ~`seconds` of CPU work."""
     from oracle import pipeline, weights
     from spr_pick_amd import synthetic
-    threads = os.cpu_count() or 1
+    # host cores this process may actually use (the GPU box exposes 256 logical CPUs but grants a
+    # share of them; oversubscribing torch's intra-op pool makes the CPU path orders slower)
+    threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("SPRK_CPU_THREADS", "16")))
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     sd = weights.make_state(weights.denoiser_shapes(), seed=0)
@@ -136,7 +138,7 @@ def main():
     dt = time.perf_counter() - t0
     L.sprk_prof_enable(0)
     launches = L.sprk_launch_count() - launches0
-    last_loss = float(torch.mean(o[P.LOSS]))
+    last_loss = float(torch.mean(o[P.LOSS].detach()))
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -77,7 +77,7 @@ struct ConvArgs {
     int ldw, NPadTotal;
     int resH, resW, resOff;
     int vec4;
-    float invImg, invInCols;
+    float invImg, invInCols, invPlane;
 };
 
 // Stage `cke` channels [c0, c0+cke) of the (virtual, concatenated, zero-padded) conv input
@@ -90,29 +90,31 @@ struct TileSrc {
 
 __device__ __forceinline__ void stage_input(float *in_lds, const TileSrc &s, int n0, int iy0, int ix0, int NI,
                                             int inRows, int inCols, int pitch, int cplane, float invImg,
-                                            float invInCols, int c0, int cke, int tid) {
+                                            float invInCols, float invPlane, int c0, int cke, int tid) {
+    // one flat index over (channel, image, row, col): every thread keeps several independent
+    // loads in flight whatever the tile shape (a 64-pixel 1x1 tile has only 64 plane elements)
     const int imgElems = inRows * inCols;
     const int planeElems = NI * imgElems;
     const long cs1 = (long)s.H1 * s.W1, cs2 = (long)s.Hin * s.Win;
-    for (int e = tid; e < planeElems; e += kThreads) {
+    const int total = cke * planeElems;
+#pragma unroll 4
+    for (int idx = tid; idx < total; idx += kThreads) {
+        const int cl = fast_div(idx, invPlane);
+        const int e = idx - cl * planeElems;
         const int il = fast_div(e, invImg);
         const int rem = e - il * imgElems;
         const int r = fast_div(rem, invInCols);
         const int col = rem - r * inCols;
         const int n = n0 + il, iy = iy0 + r, ix = ix0 + col;
-        const bool ok = n < s.N && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
-        long g1 = 0, g2 = 0;
-        if (ok) {
-            g1 = (long)n * s.C1 * cs1 + (s.up1 ? (long)(iy >> 1) * s.W1 + (ix >> 1) : (long)iy * s.W1 + ix);
-            g2 = (long)n * s.C2 * cs2 + (long)iy * s.Win + ix;
+        const int c = c0 + cl;
+        float v = 0.f;
+        if (n < s.N && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win) {
+            if (c < s.C1)
+                v = s.x[((long)n * s.C1 + c) * cs1 + (s.up1 ? (long)(iy >> 1) * s.W1 + (ix >> 1) : (long)iy * s.W1 + ix)];
+            else
+                v = s.x2[((long)n * s.C2 + (c - s.C1)) * cs2 + (long)iy * s.Win + ix];
         }
-        const int lo = (il * inRows + r) * pitch + col;
-        for (int cl = 0; cl < cke; ++cl) {
-            const int c = c0 + cl;
-            float v = 0.f;
-            if (ok) v = c < s.C1 ? s.x[g1 + c * cs1] : s.x2[g2 + (c - s.C1) * cs2];
-            in_lds[cl * cplane + lo] = v;
-        }
+        in_lds[cl * cplane + (il * inRows + r) * pitch + col] = v;
     }
 }
 
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
             cke_prev = cke;
         }
         stage_input(in_lds, src, n0, iy0, ix0, NI, a.inRows, a.inCols, a.pitch, a.cplane, a.invImg, a.invInCols,
-                    c0, cke, tid);
+                    a.invPlane, c0, cke, tid);
         {
             const int rowbase = (c0 / a.CK) * a.R4;
             constexpr int q4 = NT * 4;
@@ -264,7 +266,7 @@ struct WgArgs {
     int ioffN;               // ints reserved for the k-row offset table
     int inRows, inCols, pitch, cplane;
     int gstride;
-    float invImg, invInCols;
+    float invImg, invInCols, invPlane;
 };
 
 template <int IT, int NT>
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_mfma_kernel(const WgArgs 
         const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
         __syncthreads();
         stage_input(x_lds, src, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, NI, a.inRows, a.inCols,
-                    a.pitch, a.cplane, a.invImg, a.invInCols, c0, cke, tid);
+                    a.pitch, a.cplane, a.invImg, a.invInCols, a.invPlane, c0, cke, tid);
         for (int e = tid; e < NT * 16 * 64; e += kThreads) {
             const int col = e >> 6, p = e & 63;
             const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
@@ -580,12 +582,16 @@ int pad_to_residue(int raw, int residue) {  // smallest v >= raw with v % 32 == 
 bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stride, int dil, FwdPlan *p) {
     const int KHW = KH * KW;
     const int ntile = sprk::cdiv(Nn, 16);
-    int NT = 1;
-    for (int cand : {6, 4, 3, 2, 1})
-        if (ntile % cand == 0) {
+    // N tiles per block: every block re-stages the input tile, so fewer, wider blocks win; the
+    // last block may be ragged (its surplus columns are zero weights, never stored)
+    int NT = 1, best = 1 << 30;
+    for (int cand : {6, 4, 3, 2, 1}) {
+        const int cost = sprk::cdiv(ntile, cand) * (cand + 2);
+        if (cost < best) {
+            best = cost;
             NT = cand;
-            break;
         }
+    }
     int MT = 4;
     auto geometry = [&](int mt, int nt) {
         const int TM = 64 * mt;
@@ -601,7 +607,7 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
         p->tilesX = sprk::cdiv(Wo, TC);
         p->tilesY = sprk::cdiv(Ho, TR);
         p->imgGroups = sprk::cdiv(Nimg, NI);
-        p->nblkN = ntile / nt;
+        p->nblkN = sprk::cdiv(ntile, nt);
         p->inRows = (TR - 1) * stride + (KH - 1) * dil + 1;
         p->inCols = (TC - 1) * stride + (KW - 1) * dil + 1;
         p->pitch = p->inCols;
@@ -618,7 +624,7 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
         blocks = geometry(MT, NT);
     }
     p->ldw = (NT % 2) ? NT * 16 : NT * 16 + 16;
-    p->NPadTotal = ntile * 16;
+    p->NPadTotal = p->nblkN * NT * 16;
     int CK = std::max(1, std::min(Ck, KHW == 1 ? 32 : std::max(1, 72 / KHW)));
     auto lds = [&](int ck) {
         const int r4 = sprk::roundup(ck * KHW, 4);
@@ -668,6 +674,7 @@ void fill_args(ConvArgs &a, const FwdPlan &p) {
     a.NPadTotal = p.NPadTotal;
     a.invImg = 1.0f / (float)(p.inRows * p.inCols);
     a.invInCols = 1.0f / (float)p.inCols;
+    a.invPlane = 1.0f / (float)(((64 * p.MT) >> (p.lgTC + p.lgTR)) * p.inRows * p.inCols);
 }
 
 int check_geom(const sprk_conv_geom *g) {
@@ -691,14 +698,16 @@ struct WgPlan {
 bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     const int KHW = g->KH * g->KW, Cin = g->C1 + g->C2;
     const int ntile = sprk::cdiv(g->Cout, 16);
-    int NT = 1;
-    for (int cand : {6, 4, 3, 2, 1})
-        if (ntile % cand == 0) {
+    int NT = 1, best = 1 << 30;
+    for (int cand : {6, 4, 3, 2, 1}) {
+        const int cost = sprk::cdiv(ntile, cand) * (cand + 2);
+        if (cost < best) {
+            best = cost;
             NT = cand;
-            break;
         }
+    }
     p->NT = NT;
-    p->nblkN = ntile / NT;
+    p->nblkN = sprk::cdiv(ntile, NT);
     const int TM = 64;
     int TC = std::min(sprk::pow2_ceil(g->Wout), 64);
     if (g->dil * (g->KW - 1) >= 8) TC = std::min(TC, 8);
@@ -733,7 +742,7 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     if (itw > 5) return false;
     p->ldsBytes = lds(CKW);
     const int per = p->nChunks * p->nblkN;
-    int groups = std::max(1, std::min(p->nTiles, sprk::cdiv(1024, per)));
+    int groups = std::max(1, std::min(p->nTiles, sprk::cdiv(768, per)));
     p->tilesPerGroup = sprk::cdiv(p->nTiles, groups);
     p->groups = sprk::cdiv(p->nTiles, p->tilesPerGroup);
     return true;
@@ -902,6 +911,7 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     a.inRows = p.inRows; a.inCols = p.inCols; a.pitch = p.pitch; a.cplane = p.cplane; a.gstride = p.gstride;
     a.invImg = 1.0f / (float)(p.inRows * p.inCols);
     a.invInCols = 1.0f / (float)p.inCols;
+    a.invPlane = 1.0f / (float)((64 >> (p.lgTC + p.lgTR)) * p.inRows * p.inCols);
     dim3 grid(p.groups, p.nChunks, p.nblkN);
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * g->KH * g->KW;
     sprk::prof_begin(1, flops, s);

@@ -109,20 +109,28 @@ class _Conv2dFn(torch.autograd.Function):
             ws = _ws(nb, gy)
             check(L.sprk_conv2d_bwd_weight(_p(x), _p(x2), _p(gpre), _p(gw), ctypes.byref(g), _p(ws), nb, _stream()),
                   "sprk_conv2d_bwd_weight")
-        need_x = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
-        if need_x:
-            gin = torch.empty((g.N, g.C1 + g.C2, g.Hin, g.Win), dtype=torch.float32, device=gy.device)
-            nb = L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(g))
+        need0 = ctx.needs_input_grad[0]
+        need1 = x2 is not None and ctx.needs_input_grad[1]
+        if need0 or need1:
+            gd, wd = g, w
+            if g.C2 and not need1:
+                # the skip source needs no gradient (the raw image x0 of decode_block_1): only the
+                # first C1 input channels are back-propagated
+                gd = ConvGeom(g.N, g.C1, 0, g.Hin, g.Win, g.up1, g.Cout, g.Hout, g.Wout, g.KH, g.KW, g.stride, g.dil,
+                              g.pad_top, g.pad_left)
+                wd = w[:, :g.C1].contiguous()
+            gin = torch.empty((gd.N, gd.C1 + gd.C2, gd.Hin, gd.Win), dtype=torch.float32, device=gy.device)
+            nb = L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(gd))
             ws = _ws(nb, gy)
-            check(L.sprk_conv2d_bwd_data(_p(gpre), _p(w), _p(gin), ctypes.byref(g), _p(ws), nb, _stream()),
+            check(L.sprk_conv2d_bwd_data(_p(gpre), _p(wd), _p(gin), ctypes.byref(gd), _p(ws), nb, _stream()),
                   "sprk_conv2d_bwd_data")
-            if g.C2 == 0 and not g.up1:
+            if gd.C2 == 0 and not gd.up1:
                 gx = gin
             else:
                 gx = torch.empty_like(x)
-                gx2 = torch.empty_like(x2) if x2 is not None else None
-                check(L.sprk_concat_up_bwd(_p(gin), _p(gx), _p(gx2), g.N, g.C1, g.C2, g.Hin, g.Win, g.up1, _stream()),
-                      "sprk_concat_up_bwd")
+                gx2 = torch.empty_like(x2) if gd.C2 else None
+                check(L.sprk_concat_up_bwd(_p(gin), _p(gx), _p(gx2), gd.N, gd.C1, gd.C2, gd.Hin, gd.Win, gd.up1,
+                                           _stream()), "sprk_concat_up_bwd")
         return gx, gx2, gw, gb, None, None, None, None, None
 
 
