@@ -22,7 +22,13 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;       // 4 compute waves (one per SIMD)
+// Optional dedicated DMA loader waves (measured slower than letting the 4 MFMA waves issue their own
+// share of the DMA: LDS-DMA issue is paced by the CU's address path, not by the issuing wave): 0 = off.
+constexpr int kLoaders = 0;
+constexpr int kBlock = kThreads + 64 * kLoaders;
+constexpr int kIssuers = kLoaders ? kLoaders : 4;          // waves that share the DMA issue
+constexpr int kIssueThreads = kLoaders ? 64 * kLoaders : kThreads;
 constexpr float kLeak = 0.1f;
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -32,31 +38,104 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // ------------------------------------------------------------------------------------------
-// weight transform:  W[Cout][Cin][KHW]  ->  Wt[rows][NPad]   (rows = k in chunked order)
+// weight transform:  W[Cout][Cin][KHW]  ->  Wt[nblk][rows][ldw]   (rows = k in chunked order)
 //   mode 0 (forward):        GEMM-k channel = cin,  n = cout, tap as is
 //   mode 1 (backward-data):  GEMM-k channel = cout, n = cin,  tap flipped
 // Row order: chunks of CK k-channels; inside a chunk row = tap * cke + cl (cke = channels
 // actually present in the chunk); every chunk occupies R4 = roundup4(CK*KHW) rows.
+// Each N-block (NT*16 output channels) is stored as its own [rows][ldw] slab with the LDS row
+// stride ldw (zero padded), so a chunk of a slab is one contiguous run that LDS-DMA copies 1:1.
+// The first 256 floats of the workspace are zeroed: the DMA source of out-of-image lanes.
 // ------------------------------------------------------------------------------------------
-__global__ void weight_transform_kernel(const float *__restrict__ w, float *__restrict__ wt, int Cout, int Cin,
-                                        int KHW, int mode, int CK, int R4, int rows, int NPad) {
+constexpr int kZeroFloats = 256;
+
+__global__ void weight_transform_kernel(const float *__restrict__ w, float *__restrict__ ws, int Cout, int Cin,
+                                        int KHW, int mode, int CK, int R4, int rows, int NT16, int ldw, int nblk) {
     const int Ck = mode == 0 ? Cin : Cout;   // channels along GEMM-k
     const int Nn = mode == 0 ? Cout : Cin;   // GEMM-n extent
-    const long total = (long)rows * NPad;
+    const long total = (long)nblk * rows * ldw + kZeroFloats;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int row = (int)(e / NPad), n = (int)(e - (long)row * NPad);
-        const int q = row / R4, rr = row - q * R4;
-        const int cke = min(CK, Ck - q * CK);
         float v = 0.f;
-        if (n < Nn && rr < cke * KHW) {
-            const int tap = rr / cke, cl = rr - tap * cke;
-            const int ck = q * CK + cl;
-            if (mode == 0)
-                v = w[((long)n * Cin + ck) * KHW + tap];
-            else
-                v = w[((long)ck * Cin + n) * KHW + (KHW - 1 - tap)];
+        if (e >= kZeroFloats) {
+            long t = e - kZeroFloats;
+            const int col = (int)(t % ldw);
+            t /= ldw;
+            const int row = (int)(t % rows);
+            const int nb = (int)(t / rows);
+            const int n = nb * NT16 + col;
+            const int q = row / R4, rr = row - q * R4;
+            const int cke = min(CK, Ck - q * CK);
+            if (col < NT16 && n < Nn && rr < cke * KHW) {
+                const int tap = rr / cke, cl = rr - tap * cke;
+                const int ck = q * CK + cl;
+                if (mode == 0)
+                    v = w[((long)n * Cin + ck) * KHW + tap];
+                else
+                    v = w[((long)ck * Cin + n) * KHW + (KHW - 1 - tap)];
+            }
         }
-        wt[e] = v;
+        ws[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA staging (global_load_lds: HBM/L2 -> LDS without passing through VGPRs)
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ void dma4(const float *src, float *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(src, (lds_void *)lds_wave_base, 4, 0, 0);
+}
+__device__ __forceinline__ void dma16(const float *src, float *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(src, (lds_void *)lds_wave_base, 16, 0, 0);
+}
+
+// Source of the (virtual) conv input: channel concat of x (optionally 2x nearest-upsampled on
+// the fly) and x2, zero outside the image.
+struct TileSrc {
+    const float *x, *x2, *zeros;
+    int N, C1, C2, Hin, Win, up1, H1, W1;
+};
+
+// Stage `cke` channels [c0, c0+cke) of the input tile whose top-left input coordinate is
+// (iy0, ix0), first image n0, into LDS laid out [cl][il][row][col] (row pitch = inCols, channel
+// stride cplane).  The [il][row][col] plane is contiguous, so 64 consecutive plane elements are
+// one wave-wide DMA; lanes outside the image read the zero block instead.
+// vec4: plane rows are 16-byte aligned runs in global memory (1x1 convs): 256 elements per DMA.
+__device__ __forceinline__ void stage_input_dma(float *in_lds, const TileSrc &s, int n0, int iy0, int ix0, int NI,
+                                                int inRows, int inCols, int cplane, float invImg, float invInCols,
+                                                int c0, int cke, int lw, int lane, int vec4) {
+    const int imgElems = inRows * inCols;
+    const int planeElems = NI * imgElems;
+    const long cs1 = (long)s.H1 * s.W1, cs2 = (long)s.Hin * s.Win;
+    const int per = vec4 ? 256 : 64;
+    const int nGroups = (planeElems + per - 1) / per;
+    for (int gi = lw; gi < nGroups; gi += kIssuers) {
+        const int e = vec4 ? gi * 256 + lane * 4 : gi * 64 + lane;
+        const int il = fast_div(e, invImg);
+        const int rem = e - il * imgElems;
+        const int r = fast_div(rem, invInCols);
+        const int col = rem - r * inCols;
+        const int n = n0 + il, iy = iy0 + r, ix = ix0 + col;
+        const bool inb = e < planeElems;
+        const bool ok = inb && n < s.N && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
+        const float *p1 = s.x + ((long)n * s.C1 + c0) * cs1 +
+                          (s.up1 ? (long)(iy >> 1) * s.W1 + (ix >> 1) : (long)iy * s.W1 + ix);
+        const float *p2 = s.x2 + ((long)n * s.C2 + (c0 - s.C1)) * cs2 + (long)iy * s.Win + ix;
+        float *dst = in_lds + gi * per;
+        for (int cl = 0; cl < cke; ++cl) {
+            const float *src = (c0 + cl < s.C1) ? p1 : p2;
+            if (!ok) src = s.zeros + lane * 4;
+            if (inb) {
+                if (vec4)
+                    dma16(src, dst);
+                else
+                    dma4(src, dst);
+            }
+            p1 += cs1;
+            p2 += cs2;
+            dst += cplane;
+        }
     }
 }
 
@@ -64,7 +143,7 @@ __global__ void weight_transform_kernel(const float *__restrict__ w, float *__re
 // forward / backward-data MFMA kernel
 // ------------------------------------------------------------------------------------------
 struct ConvArgs {
-    const float *x, *x2, *wT, *bias, *scale, *shift, *res;
+    const float *x, *x2, *wT, *zeros, *bias, *scale, *shift, *res;
     float *y;
     int N, C1, C2, Hin, Win, up1, H1, W1;
     int Cout, Hout, Wout;
@@ -72,60 +151,24 @@ struct ConvArgs {
     int act;
     int lgTC, lgTR;
     int tilesX, tilesY;
-    int CK, R4;
+    int CK, R4, rows;
     int inRows, inCols, pitch, cplane;
-    int ldw, NPadTotal;
+    int ldw;
     int resH, resW, resOff;
-    int vec4;
-    float invImg, invInCols, invPlane;
+    int vec4, in4;
+    float invImg, invInCols;
 };
-
-// Stage `cke` channels [c0, c0+cke) of the (virtual, concatenated, zero-padded) conv input
-// for the tile whose top-left input coordinate is (iy0, ix0) and first image is n0.
-// LDS layout: [cl][il][row][col] with row pitch `pitch` and channel stride `cplane`.
-struct TileSrc {
-    const float *x, *x2;
-    int N, C1, C2, Hin, Win, up1, H1, W1;
-};
-
-__device__ __forceinline__ void stage_input(float *in_lds, const TileSrc &s, int n0, int iy0, int ix0, int NI,
-                                            int inRows, int inCols, int pitch, int cplane, float invImg,
-                                            float invInCols, float invPlane, int c0, int cke, int tid) {
-    // one flat index over (channel, image, row, col): every thread keeps several independent
-    // loads in flight whatever the tile shape (a 64-pixel 1x1 tile has only 64 plane elements)
-    const int imgElems = inRows * inCols;
-    const int planeElems = NI * imgElems;
-    const long cs1 = (long)s.H1 * s.W1, cs2 = (long)s.Hin * s.Win;
-    const int total = cke * planeElems;
-#pragma unroll 4
-    for (int idx = tid; idx < total; idx += kThreads) {
-        const int cl = fast_div(idx, invPlane);
-        const int e = idx - cl * planeElems;
-        const int il = fast_div(e, invImg);
-        const int rem = e - il * imgElems;
-        const int r = fast_div(rem, invInCols);
-        const int col = rem - r * inCols;
-        const int n = n0 + il, iy = iy0 + r, ix = ix0 + col;
-        const int c = c0 + cl;
-        float v = 0.f;
-        if (n < s.N && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win) {
-            if (c < s.C1)
-                v = s.x[((long)n * s.C1 + c) * cs1 + (s.up1 ? (long)(iy >> 1) * s.W1 + (ix >> 1) : (long)iy * s.W1 + ix)];
-            else
-                v = s.x2[((long)n * s.C2 + (c - s.C1)) * cs2 + (long)iy * s.Win + ix];
-        }
-        in_lds[cl * cplane + (il * inRows + r) * pitch + col] = v;
-    }
-}
 
 template <int MT, int NT>
-__global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(kBlock) void conv_mfma_kernel(const ConvArgs a) {
+    // LDS: koff[2][R4] | stage 0: input[CK*cplane] weights[R4*ldw] | stage 1: ...
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int *koff = reinterpret_cast<int *>(smem);
-    float *in_lds = smem + a.R4;
-    float *w_lds = in_lds + a.CK * a.cplane;
+    const int stageFloats = a.CK * a.cplane + a.R4 * a.ldw;
+    int *koff_base = reinterpret_cast<int *>(smem);
+    float *stage_base = smem + 2 * a.R4;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr int TM = 64 * MT;
     const int lgT = a.lgTC + a.lgTR;
@@ -141,10 +184,13 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
     const int KHW = a.KH * a.KW, Cin = a.C1 + a.C2;
     const int TCm = (1 << a.lgTC) - 1, TRm = (1 << a.lgTR) - 1;
 
+    const bool loader = kLoaders ? wave >= 4 : true;   // wave-uniform roles
+    const bool compute = kLoaders ? wave < 4 : true;
+    const int lw = kLoaders ? wave - 4 : wave, ltid = kLoaders ? tid - kThreads : tid;
     int pixbase[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int p = (wave * MT + mt) * 16 + l15;
+        const int p = ((wave & 3) * MT + mt) * 16 + l15;
         const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
         pixbase[mt] = (il * a.inRows + r * a.stride) * a.pitch + c * a.stride;
     }
@@ -154,15 +200,19 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    TileSrc src{a.x, a.x2, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1};
-    int cke_prev = -1;
-    for (int c0 = 0; c0 < Cin; c0 += a.CK) {
+    TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1};
+    const float *wslab = a.wT + (long)nb * a.rows * a.ldw;
+    int tab_cke0 = -1, tab_cke1 = -1;
+
+    // issue the DMA of chunk starting at channel c0 into stage `b`
+    auto issue = [&](int c0, int b) {
         const int cke = min(a.CK, Cin - c0);
         const int kvalid = cke * KHW;
         const int kchunk = (kvalid + 3) & ~3;
-        __syncthreads();  // previous chunk fully consumed
-        if (cke != cke_prev) {
-            for (int k = tid; k < kchunk; k += kThreads) {
+        int *koff = koff_base + b * a.R4;
+        const int have = b ? tab_cke1 : tab_cke0;
+        if (cke != have) {
+            for (int k = ltid; k < kchunk; k += kIssueThreads) {
                 int v = 0;
                 if (k < kvalid) {
                     const int tap = k / cke, cl = k - tap * cke;
@@ -171,38 +221,64 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
                 }
                 koff[k] = v;
             }
-            cke_prev = cke;
+            if (b) tab_cke1 = cke; else tab_cke0 = cke;
         }
-        stage_input(in_lds, src, n0, iy0, ix0, NI, a.inRows, a.inCols, a.pitch, a.cplane, a.invImg, a.invInCols,
-                    a.invPlane, c0, cke, tid);
-        {
-            const int rowbase = (c0 / a.CK) * a.R4;
-            constexpr int q4 = NT * 4;
-            const float *wsrc = a.wT + (long)rowbase * a.NPadTotal + nb * (NT * 16);
-            for (int e = tid; e < kchunk * q4; e += kThreads) {
-                const int r = e / q4, q = e - r * q4;
-                const float4 v = *reinterpret_cast<const float4 *>(wsrc + (long)r * a.NPadTotal + q * 4);
-                *reinterpret_cast<float4 *>(w_lds + r * a.ldw + q * 4) = v;
-            }
+        float *in_lds = stage_base + b * stageFloats;
+        float *w_lds = in_lds + a.CK * a.cplane;
+        stage_input_dma(in_lds, src, n0, iy0, ix0, NI, a.inRows, a.inCols, a.cplane, a.invImg, a.invInCols, c0, cke,
+                        lw, lane, a.in4);
+        const float *wsrc = wslab + (long)(c0 / a.CK) * a.R4 * a.ldw;
+        const int total4 = (kchunk * a.ldw) >> 2;
+        for (int gi = lw; gi * 64 < total4; gi += kIssuers) {
+            const int idx = gi * 64 + lane;
+            if (idx < total4) dma16(wsrc + idx * 4, w_lds + gi * 256);
         }
+    };
+
+    if (loader) issue(0, 0);
+    int ci = 0;
+    for (int c0 = 0; c0 < Cin; c0 += a.CK, ++ci) {
+        // every wave's DMA of this chunk has landed (vmcnt(0)) and every wave is done reading the
+        // other stage (previous chunk) once all have passed the barrier
         __syncthreads();
-        const int nkq = kchunk >> 2;
-        for (int kq = 0; kq < nkq; ++kq) {
-            const int krow = kq * 4 + lq;
-            const int ko = koff[krow];
-            float av[MT], bv[NT];
+        if (loader && c0 + a.CK < Cin) issue(c0 + a.CK, (ci + 1) & 1);
+        if (!compute) continue;
+        const int b = ci & 1;
+        const int cke = min(a.CK, Cin - c0);
+        const int nkq = (cke * KHW + 3) >> 2;
+        const int *koff = koff_base + b * a.R4;
+        const float *in_lds = stage_base + b * stageFloats;
+        const float *w_lds = in_lds + a.CK * a.cplane;
+        // software pipeline: the operands of step kq+1 are fetched from LDS under the MFMAs of step kq
+        float av[MT], bv[NT];
+        {
+            const int ko = koff[lq];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) av[mt] = in_lds[pixbase[mt] + ko];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = w_lds[krow * a.ldw + nt * 16 + l15];
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = w_lds[lq * a.ldw + nt * 16 + l15];
+        }
+        for (int kq = 0; kq < nkq; ++kq) {
+            const int krow = min(kq + 1, nkq - 1) * 4 + lq;  // the last step re-reads itself (unused)
+            const int ko = koff[krow];
+            float an[MT], bn[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) an[mt] = in_lds[pixbase[mt] + ko];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bn[nt] = w_lds[krow * a.ldw + nt * 16 + l15];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = an[mt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
         }
     }
 
+    if (!compute) return;  // no barrier below
     // epilogue: D layout col(n) = lane&15, row(m) = (lane>>4)*4 + reg
     const long planeO = (long)a.Hout * a.Wout;
 #pragma unroll
@@ -252,32 +328,60 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_kernel(const ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// backward-weight MFMA kernel:  partial[group][Cout][Cin][KHW]
+// backward-weight MFMA kernel:  partial[group][k = c*KHW + tap][CoutP]
+//   D[k-row][cout] += X[k-row][pixel] * G[pixel][cout] over the block's 64-pixel tiles; both
+//   operands arrive by LDS-DMA, double buffered, so the next tile streams in under the MFMAs.
+//   The G tile is stored [cout][64 pixels] with its 16-byte chunks XOR-swizzled by (cout & 7)
+//   (applied on the DMA source address; the image itself is lane-linear) -> 2-way conflicts only.
 // ------------------------------------------------------------------------------------------
 struct WgArgs {
-    const float *x, *x2, *gy;
+    const float *x, *x2, *gy, *zeros;
     float *partial;
     int N, C1, C2, Hin, Win, up1, H1, W1;
-    int Cout, Hout, Wout;
+    int Cout, CoutP, Hout, Wout;
     int KH, KW, stride, dil, padT, padL;
     int lgTC, lgTR;          // 64-pixel tile
     int tilesX, tilesY, nTiles, tilesPerGroup;
     int CKW;                 // input channels per blockIdx.y
     int ioffN;               // ints reserved for the k-row offset table
     int inRows, inCols, pitch, cplane;
-    int gstride;
-    float invImg, invInCols, invPlane;
+    int xrow, g4;
+    float invImg, invInCols;
 };
 
+// one 64-pixel tile: 16 k-steps of MFMAs on NIT k-tiles x NT cout-tiles (branch free, fully unrolled
+// so that the LDS reads of step ks+1 are scheduled under the MFMAs of step ks)
+template <int NIT, int IT, int NT>
+__device__ __forceinline__ void wgrad_tile(f32x4 (&acc)[IT][NT], const float *x_lds, const float *g_lds,
+                                           const int *pixoff, const int (&ioffv)[IT], int l15, int lq, int gsw,
+                                           int xrow) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const int gp = ((ks ^ gsw) << 2) | lq;
+        const int xo = xrow ? gp : pixoff[ks * 4 + lq];
+        float av[NIT], bv[NT];
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) av[t] = x_lds[ioffv[t] + xo];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = g_lds[(nt * 16 + l15) * 64 + gp];
+#pragma unroll
+        for (int t = 0; t < NIT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[nt], acc[t][nt], 0, 0, 0);
+    }
+}
+
 template <int IT, int NT>
-__global__ __launch_bounds__(kThreads) void conv_wgrad_mfma_kernel(const WgArgs a) {
+__global__ __launch_bounds__(kBlock) void conv_wgrad_mfma_kernel(const WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *ioff = reinterpret_cast<int *>(smem);          // [ioffN]
     int *pixoff = ioff + a.ioffN;                       // [64]
-    float *x_lds = smem + a.ioffN + 64;                 // [CKW * cplane]
-    float *g_lds = x_lds + a.CKW * a.cplane;            // [NT*16 * gstride]
+    float *stage_base = smem + a.ioffN + 64;            // 2 x { x[CKW*cplane], g[NT*16*64] }
+    const int stageFloats = a.CKW * a.cplane + NT * 16 * 64;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int lgT = a.lgTC + a.lgTR;
     const int NI = 64 >> lgT;
@@ -288,8 +392,13 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_mfma_kernel(const WgArgs 
     const int kvalid = cke * KHW;
     const int nIT = (kvalid + 15) >> 4;
     const int co0 = blockIdx.z * (NT * 16);
+    const long planeO = (long)a.Hout * a.Wout;
+    const long planeI = (long)a.Hin * a.Win;
+    const bool loader = kLoaders ? wave >= 4 : true;   // wave-uniform roles
+    const bool compute = kLoaders ? wave < 4 : true;
+    const int lw = kLoaders ? wave - 4 : wave;
 
-    for (int k = tid; k < nIT * 16; k += kThreads) {
+    for (int k = tid; k < nIT * 16; k += kBlock) {
         int v = 0;
         if (k < kvalid) {
             const int tap = k / cke, cl = k - tap * cke;
@@ -302,11 +411,60 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_mfma_kernel(const WgArgs 
         const int il = tid >> lgT, r = (tid >> a.lgTC) & TRm, c = tid & TCm;
         pixoff[tid] = (il * a.inRows + r * a.stride) * a.pitch + c * a.stride;
     }
-    __syncthreads();
+
+    TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1};
+    // rows of 64 pixels, 16-byte chunks XOR-swizzled by (row & 7): LDS chunk (row, qs) <- pixels
+    // 4q..4q+3, q = qs ^ (row & 7).  base: tensor [N][C][H*W]; row r is channel ch0 + r.
+    auto stage_rows16 = [&](float *dst, const float *base, int C, long plane, int W, int H, int ch0, int nrows,
+                            int chlim, int n0, int oy0, int ox0) {
+        for (int gi = lw; gi * 4 < nrows; gi += kIssuers) {
+            const int idx = gi * 64 + lane;
+            const int row = idx >> 4, qs = idx & 15;
+            const int p = (qs ^ (row & 7)) << 2;
+            const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
+            const int n = n0 + il, oy = oy0 + r, ox = ox0 + c, ch = ch0 + row;
+            const float *s = a.zeros + lane * 4;
+            if (ch < chlim && n < a.N && oy < H && ox < W) s = base + ((long)n * C + ch) * plane + (long)oy * W + ox;
+            if (row < nrows) dma16(s, dst + gi * 256);
+        }
+    };
+    auto issue = [&](int tile, int b) {
+        int t = tile;
+        const int tx = t % a.tilesX;
+        t /= a.tilesX;
+        const int ty = t % a.tilesY;
+        const int ig = t / a.tilesY;
+        const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
+        float *x_lds = stage_base + b * stageFloats;
+        float *g_lds = x_lds + a.CKW * a.cplane;
+        if (a.xrow)
+            stage_rows16(x_lds, a.x, a.C1, planeI, a.Win, a.Hin, c0, cke, Cin, n0, oy0, ox0);
+        else
+            stage_input_dma(x_lds, src, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, NI, a.inRows, a.inCols,
+                            a.cplane, a.invImg, a.invInCols, c0, cke, lw, lane, 0);
+        if (a.g4) {
+            stage_rows16(g_lds, a.gy, a.Cout, planeO, a.Wout, a.Hout, co0, NT * 16, a.Cout, n0, oy0, ox0);
+        } else {
+            for (int col = lw; col < NT * 16; col += kIssuers) {
+                const int p = (((lane >> 2) ^ (col & 7)) << 2) | (lane & 3);
+                const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
+                const int n = n0 + il, oy = oy0 + r, ox = ox0 + c, co = co0 + col;
+                const float *s = a.zeros + lane;
+                if (co < a.Cout && n < a.N && oy < a.Hout && ox < a.Wout)
+                    s = a.gy + ((long)n * a.Cout + co) * planeO + (long)oy * a.Wout + ox;
+                dma4(s, g_lds + col * 64);
+            }
+        }
+    };
+
+    const int t_begin = blockIdx.x * a.tilesPerGroup;
+    const int t_end = min(a.nTiles, t_begin + a.tilesPerGroup);
+    if (loader && t_begin < t_end) issue(t_begin, 0);
+    __syncthreads();  // tables visible
     int ioffv[IT];
 #pragma unroll
     for (int t = 0; t < IT; ++t) {
-        const int it = wave + 4 * t;
+        const int it = (wave & 3) + 4 * t;
         ioffv[t] = it < nIT ? ioff[it * 16 + l15] : 0;
     }
     f32x4 acc[IT][NT];
@@ -314,52 +472,44 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_mfma_kernel(const WgArgs 
     for (int t = 0; t < IT; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int gsw = l15 & 7;
+    const int myIT = (compute && nIT > wave) ? (nIT - wave + 3) >> 2 : 0;  // k-tiles owned by this wave (uniform)
 
-    TileSrc src{a.x, a.x2, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1};
-    const long planeO = (long)a.Hout * a.Wout;
-    const int t_begin = blockIdx.x * a.tilesPerGroup;
-    const int t_end = min(a.nTiles, t_begin + a.tilesPerGroup);
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        int b = tile;
-        const int tx = b % a.tilesX;
-        b /= a.tilesX;
-        const int ty = b % a.tilesY;
-        const int ig = b / a.tilesY;
-        const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
-        __syncthreads();
-        stage_input(x_lds, src, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, NI, a.inRows, a.inCols,
-                    a.pitch, a.cplane, a.invImg, a.invInCols, a.invPlane, c0, cke, tid);
-        for (int e = tid; e < NT * 16 * 64; e += kThreads) {
-            const int col = e >> 6, p = e & 63;
-            const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
-            const int n = n0 + il, oy = oy0 + r, ox = ox0 + c, co = co0 + col;
-            float v = 0.f;
-            if (co < a.Cout && n < a.N && oy < a.Hout && ox < a.Wout)
-                v = a.gy[((long)n * a.Cout + co) * planeO + (long)oy * a.Wout + ox];
-            g_lds[col * a.gstride + p] = v;
-        }
-        __syncthreads();
+    int bsel = 0;
+    for (int tile = t_begin; tile < t_end; ++tile, bsel ^= 1) {
+        __syncthreads();  // this tile landed everywhere; previous tile fully consumed
+        if (loader && tile + 1 < t_end) issue(tile + 1, bsel ^ 1);
+        if (!compute) continue;
+        const float *x_lds = stage_base + bsel * stageFloats;
+        const float *g_lds = x_lds + a.CKW * a.cplane;
+        if (myIT >= IT)
+            wgrad_tile<IT, IT, NT>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw, a.xrow);
+        else if (IT > 1 && myIT == IT - 1)
+            wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NT>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw, a.xrow);
+        else if (myIT > 0) {
+            // short tail chunk: predicate per k-tile (rare: last channel chunk of a layer)
 #pragma unroll 2
-        for (int ks = 0; ks < 16; ++ks) {
-            const int p = ks * 4 + lq;
-            const int po = pixoff[p];
-            float av[IT], bv[NT];
+            for (int ks = 0; ks < 16; ++ks) {
+                const int gp = ((ks ^ gsw) << 2) | lq;
+                const int xo = a.xrow ? gp : pixoff[ks * 4 + lq];
+                float bv[NT];
 #pragma unroll
-            for (int t = 0; t < IT; ++t) av[t] = x_lds[ioffv[t] + po];
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = g_lds[(nt * 16 + l15) * 64 + gp];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = g_lds[(nt * 16 + l15) * a.gstride + p];
+                for (int t = 0; t < IT; ++t) {
+                    if (t < myIT) {
+                        const float av = x_lds[ioffv[t] + xo];
 #pragma unroll
-            for (int t = 0; t < IT; ++t) {
-                if (wave + 4 * t < nIT) {  // wave-uniform
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[nt], acc[t][nt], 0, 0, 0);
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[t][nt], 0, 0, 0);
+                    }
                 }
             }
         }
     }
-    // write partial: D rows = k (lq*4 + reg), cols = cout (l15)
-    float *dst = a.partial + (long)blockIdx.x * a.Cout * Cin * KHW;
+    if (!compute) return;
+    // partial slab of this group: rows = global k (c*KHW + tap), cols = cout (64-byte runs per store)
+    float *dst = a.partial + (long)blockIdx.x * Cin * KHW * a.CoutP;
 #pragma unroll
     for (int t = 0; t < IT; ++t) {
         const int it = wave + 4 * t;
@@ -372,17 +522,23 @@ __global__ __launch_bounds__(kThreads) void conv_wgrad_mfma_kernel(const WgArgs 
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = co0 + nt * 16 + l15;
-                if (co < a.Cout) dst[((long)co * Cin + c0 + cl) * KHW + tap] = acc[t][nt][j];
+                if (co < a.CoutP) dst[((long)(c0 + cl) * KHW + tap) * a.CoutP + co] = acc[t][nt][j];
             }
         }
     }
 }
 
-__global__ void reduce_partials_kernel(const float *__restrict__ partial, float *__restrict__ out, long n, int groups) {
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) {
+// out[co][c][tap] = sum_g partial[g][(c*KHW+tap)][co]
+__global__ void reduce_partials_kernel(const float *__restrict__ partial, float *__restrict__ out, int K, int Cout,
+                                       int CoutP, int groups) {
+    const long slab = (long)K * CoutP;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < slab; e += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(e % CoutP);
+        const int k = (int)(e / CoutP);
+        if (co >= Cout) continue;
         float s = 0.f;
-        for (int g = 0; g < groups; ++g) s += partial[(long)g * n + e];
-        out[e] = s;
+        for (int g = 0; g < groups; ++g) s += partial[(long)g * slab + e];
+        out[(long)co * K + k] = s;
     }
 }
 
@@ -567,21 +723,20 @@ __global__ void concat_up_bwd_kernel(const float *__restrict__ gin, float *__res
 // ------------------------------------------------------------------------------------------
 // host-side planning
 // ------------------------------------------------------------------------------------------
+constexpr size_t kLdsLimit = 160 * 1024;
+
 struct FwdPlan {
     int MT, NT, lgTC, lgTR, tilesX, tilesY, imgGroups, nblkN;
-    int CK, R4, rows, NPadTotal;
-    int inRows, inCols, pitch, cplane, ldw;
-    size_t ldsBytes;
+    int CK, R4, rows;
+    int inRows, inCols, pitch, cplane, ldw, NI;
+    size_t ldsBytes, wsBytes;
 };
 
 int pad_to_residue(int raw, int residue) {  // smallest v >= raw with v % 32 == residue
     return raw + ((residue - raw % 32) + 32) % 32;
 }
 
-// Ck: channels along GEMM-k; Nn: GEMM-n extent; output spatial dims Ho x Wo over Nimg images
-bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stride, int dil, FwdPlan *p) {
-    const int KHW = KH * KW;
-    const int ntile = sprk::cdiv(Nn, 16);
+int pick_nt(int ntile) {
     // N tiles per block: every block re-stages the input tile, so fewer, wider blocks win; the
     // last block may be ragged (its surplus columns are zero weights, never stored)
     int NT = 1, best = 1 << 30;
@@ -592,6 +747,14 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
             NT = cand;
         }
     }
+    return NT;
+}
+
+// Ck: channels along GEMM-k; Nn: GEMM-n extent; output spatial dims Ho x Wo over Nimg images
+bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stride, int dil, FwdPlan *p) {
+    const int KHW = KH * KW;
+    const int ntile = sprk::cdiv(Nn, 16);
+    int NT = pick_nt(ntile);
     int MT = 4;
     auto geometry = [&](int mt, int nt) {
         const int TM = 64 * mt;
@@ -602,6 +765,7 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
         int NI = TM / (TC * TR);
         p->MT = mt;
         p->NT = nt;
+        p->NI = NI;
         p->lgTC = sprk::ilog2(TC);
         p->lgTR = sprk::ilog2(TR);
         p->tilesX = sprk::cdiv(Wo, TC);
@@ -610,7 +774,7 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
         p->nblkN = sprk::cdiv(ntile, nt);
         p->inRows = (TR - 1) * stride + (KH - 1) * dil + 1;
         p->inCols = (TC - 1) * stride + (KW - 1) * dil + 1;
-        p->pitch = p->inCols;
+        p->pitch = p->inCols;  // the plane must be contiguous for the LDS-DMA image
         p->cplane = pad_to_residue(NI * p->inRows * p->pitch, 16);
         return (long)p->imgGroups * p->tilesX * p->tilesY * p->nblkN;
     };
@@ -624,38 +788,58 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
         blocks = geometry(MT, NT);
     }
     p->ldw = (NT % 2) ? NT * 16 : NT * 16 + 16;
-    p->NPadTotal = p->nblkN * NT * 16;
-    int CK = std::max(1, std::min(Ck, KHW == 1 ? 32 : std::max(1, 72 / KHW)));
+    // channels per K-chunk: two stages (double buffer) should leave room for 3 workgroups per CU
     auto lds = [&](int ck) {
         const int r4 = sprk::roundup(ck * KHW, 4);
-        return (size_t)(r4 + ck * p->cplane + r4 * p->ldw) * 4;
+        return (size_t)(2 * r4 + 2 * (ck * p->cplane + r4 * p->ldw)) * 4;
     };
-    while (CK > 1 && lds(CK) > 64 * 1024) CK >>= 1;
-    if (lds(CK) > 64 * 1024) return false;
+    int CK = std::max(1, std::min(Ck, KHW == 1 ? 16 : std::max(1, 36 / KHW)));
+    while (CK > 1 && lds(CK) > 52 * 1024) CK >>= 1;
+    if (lds(CK) > kLdsLimit) return false;
     p->CK = CK;
     p->R4 = sprk::roundup(CK * KHW, 4);
     p->rows = sprk::cdiv(Ck, CK) * p->R4;
     p->ldsBytes = lds(CK);
+    p->wsBytes = ((size_t)kZeroFloats + (size_t)p->nblkN * p->rows * p->ldw) * sizeof(float);
     return true;
 }
 
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes) != hipSuccess) {
+            sprk::set_error("cannot reserve %zu bytes of LDS", bytes);
+            return SPRK_ELAUNCH;
+        }
+    }
+    return SPRK_OK;
+}
+
+template <int MT, int NT>
+int launch_fwd_one(const ConvArgs &a, const FwdPlan &p, dim3 grid, hipStream_t s) {
+    if (int rc = set_lds(conv_mfma_kernel<MT, NT>, p.ldsBytes)) return rc;
+    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(kBlock), p.ldsBytes, s, a);
+    return SPRK_OK;
+}
+
 template <int MT>
-void launch_fwd_nt(const ConvArgs &a, const FwdPlan &p, dim3 grid, hipStream_t s) {
+int launch_fwd_nt(const ConvArgs &a, const FwdPlan &p, dim3 grid, hipStream_t s) {
     switch (p.NT) {
-        case 1: hipLaunchKernelGGL((conv_mfma_kernel<MT, 1>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
-        case 2: hipLaunchKernelGGL((conv_mfma_kernel<MT, 2>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
-        case 3: hipLaunchKernelGGL((conv_mfma_kernel<MT, 3>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
-        case 4: hipLaunchKernelGGL((conv_mfma_kernel<MT, 4>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
-        default: hipLaunchKernelGGL((conv_mfma_kernel<MT, 6>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+        case 1: return launch_fwd_one<MT, 1>(a, p, grid, s);
+        case 2: return launch_fwd_one<MT, 2>(a, p, grid, s);
+        case 3: return launch_fwd_one<MT, 3>(a, p, grid, s);
+        case 4: return launch_fwd_one<MT, 4>(a, p, grid, s);
+        default: return launch_fwd_one<MT, 6>(a, p, grid, s);
     }
 }
 
-void launch_fwd(const ConvArgs &a, const FwdPlan &p, hipStream_t s) {
+int launch_fwd(const ConvArgs &a, const FwdPlan &p, hipStream_t s) {
     dim3 grid(p.imgGroups * p.tilesX * p.tilesY, p.nblkN);
     switch (p.MT) {
-        case 1: launch_fwd_nt<1>(a, p, grid, s); break;
-        case 2: launch_fwd_nt<2>(a, p, grid, s); break;
-        default: launch_fwd_nt<4>(a, p, grid, s); break;
+        case 1: return launch_fwd_nt<1>(a, p, grid, s);
+        case 2: return launch_fwd_nt<2>(a, p, grid, s);
+        default: return launch_fwd_nt<4>(a, p, grid, s);
     }
 }
 
@@ -666,15 +850,27 @@ void fill_args(ConvArgs &a, const FwdPlan &p) {
     a.tilesY = p.tilesY;
     a.CK = p.CK;
     a.R4 = p.R4;
+    a.rows = p.rows;
     a.inRows = p.inRows;
     a.inCols = p.inCols;
     a.pitch = p.pitch;
     a.cplane = p.cplane;
     a.ldw = p.ldw;
-    a.NPadTotal = p.NPadTotal;
     a.invImg = 1.0f / (float)(p.inRows * p.inCols);
     a.invInCols = 1.0f / (float)p.inCols;
-    a.invPlane = 1.0f / (float)(((64 * p.MT) >> (p.lgTC + p.lgTR)) * p.inRows * p.inCols);
+    // 16-byte DMA of the input plane: no halo columns and 4-pixel runs aligned in global memory
+    a.in4 = (a.KW == 1 && a.padL == 0 && a.stride == 1 && !a.up1 && (a.Win % 4) == 0 && p.lgTC >= 2 &&
+             (((uintptr_t)a.x | (uintptr_t)a.x2) & 15) == 0)
+                ? 1
+                : 0;
+}
+
+int transform_weights(const float *w, float *ws, int Cout, int Cin, int KHW, int mode, const FwdPlan &p,
+                      hipStream_t s) {
+    const long total = (long)p.nblkN * p.rows * p.ldw + kZeroFloats;
+    hipLaunchKernelGGL(weight_transform_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, s, w, ws, Cout, Cin, KHW,
+                       mode, p.CK, p.R4, p.rows, p.NT * 16, p.ldw, p.nblkN);
+    return sprk::check_launch("weight_transform");
 }
 
 int check_geom(const sprk_conv_geom *g) {
@@ -683,31 +879,24 @@ int check_geom(const sprk_conv_geom *g) {
     SPRK_REQUIRE(g->Hin > 0 && g->Win > 0 && g->Hout > 0 && g->Wout > 0, "conv: bad spatial dims");
     SPRK_REQUIRE(g->KH > 0 && g->KW > 0 && g->stride > 0 && g->dil > 0, "conv: bad kernel params");
     SPRK_REQUIRE(!g->up1 || (g->Hin % 2 == 0 && g->Win % 2 == 0), "conv: up1 needs even Hin/Win");
-    // the last output row/col must start inside the padded input (no reads needed beyond zero fill is fine)
     SPRK_REQUIRE((long)g->N * (g->C1 + g->C2) * g->Hin * g->Win < (1L << 40), "conv: tensor too large");
     return SPRK_OK;
 }
 
 struct WgPlan {
     int IT, NT, lgTC, lgTR, tilesX, tilesY, nTiles, tilesPerGroup, groups;
-    int CKW, nChunks, nblkN, ioffN;
-    int inRows, inCols, pitch, cplane, gstride;
-    size_t ldsBytes;
+    int CKW, nChunks, nblkN, ioffN, CoutP;
+    int inRows, inCols, pitch, cplane, xrow;
+    size_t ldsBytes, wsBytes;
 };
 
 bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     const int KHW = g->KH * g->KW, Cin = g->C1 + g->C2;
     const int ntile = sprk::cdiv(g->Cout, 16);
-    int NT = 1, best = 1 << 30;
-    for (int cand : {6, 4, 3, 2, 1}) {
-        const int cost = sprk::cdiv(ntile, cand) * (cand + 2);
-        if (cost < best) {
-            best = cost;
-            NT = cand;
-        }
-    }
+    const int NT = pick_nt(ntile);
     p->NT = NT;
     p->nblkN = sprk::cdiv(ntile, NT);
+    p->CoutP = p->nblkN * NT * 16;
     const int TM = 64;
     int TC = std::min(sprk::pow2_ceil(g->Wout), 64);
     if (g->dil * (g->KW - 1) >= 8) TC = std::min(TC, 8);
@@ -722,17 +911,23 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     p->inCols = (TC - 1) * g->stride + (g->KW - 1) * g->dil + 1;
     p->pitch = p->inCols;
     p->cplane = pad_to_residue(NI * p->inRows * p->pitch, 2);
-    p->gstride = 66;
+    // 1x1, stride 1, unpadded, single full-resolution source: the x tile is 64 contiguous pixels per
+    // channel, staged like the G tile (swizzled 64-float rows, 16-byte DMA)
+    p->xrow = (KHW == 1 && g->stride == 1 && g->pad_top == 0 && g->pad_left == 0 && !g->up1 && g->C2 == 0 &&
+               TC >= 4 && (g->Win % 4) == 0 && g->Hin == g->Hout && g->Win == g->Wout)
+                  ? 1
+                  : 0;
+    if (p->xrow) p->cplane = 64;
     // channels per chunk: up to 20 k-tiles of 16 rows (IT = 5 per wave)
     int CKW = std::max(1, std::min(Cin, (5 * 4 * 16) / KHW));
     if (KHW == 9) CKW = std::min(CKW, 32);
-    if (KHW == 1) CKW = std::min(CKW, 128);
+    if (KHW == 1) CKW = std::min(CKW, 192);
     auto lds = [&](int ck) {
         const int ioffN = sprk::roundup(sprk::roundup(ck * KHW, 16), 4);
-        return (size_t)(ioffN + 64 + ck * p->cplane + NT * 16 * p->gstride) * 4;
+        return (size_t)(ioffN + 64 + 2 * (ck * p->cplane + NT * 16 * 64)) * 4;
     };
-    while (CKW > 1 && lds(CKW) > 64 * 1024) CKW = (CKW + 1) / 2;
-    if (lds(CKW) > 64 * 1024) return false;
+    while (CKW > 1 && lds(CKW) > 150 * 1024) CKW = (CKW + 1) / 2;
+    if (lds(CKW) > kLdsLimit) return false;
     p->CKW = CKW;
     p->nChunks = sprk::cdiv(Cin, CKW);
     p->ioffN = sprk::roundup(sprk::roundup(CKW * KHW, 16), 4);
@@ -742,20 +937,28 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     if (itw > 5) return false;
     p->ldsBytes = lds(CKW);
     const int per = p->nChunks * p->nblkN;
-    int groups = std::max(1, std::min(p->nTiles, sprk::cdiv(768, per)));
+    int groups = std::max(1, std::min(p->nTiles, sprk::cdiv(512, per)));
     p->tilesPerGroup = sprk::cdiv(p->nTiles, groups);
     p->groups = sprk::cdiv(p->nTiles, p->tilesPerGroup);
+    p->wsBytes = ((size_t)kZeroFloats + (size_t)p->groups * Cin * KHW * p->CoutP) * sizeof(float);
     return true;
 }
 
+template <int IT, int NT>
+int launch_wg_one(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
+    if (int rc = set_lds(conv_wgrad_mfma_kernel<IT, NT>, p.ldsBytes)) return rc;
+    hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, NT>), grid, dim3(kBlock), p.ldsBytes, s, a);
+    return SPRK_OK;
+}
+
 template <int IT>
-void launch_wg_nt(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
+int launch_wg_nt(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
     switch (p.NT) {
-        case 1: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, 1>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
-        case 2: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, 2>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
-        case 3: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, 3>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
-        case 4: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, 4>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
-        default: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, 6>), grid, dim3(kThreads), p.ldsBytes, s, a); break;
+        case 1: return launch_wg_one<IT, 1>(a, p, grid, s);
+        case 2: return launch_wg_one<IT, 2>(a, p, grid, s);
+        case 3: return launch_wg_one<IT, 3>(a, p, grid, s);
+        case 4: return launch_wg_one<IT, 4>(a, p, grid, s);
+        default: return launch_wg_one<IT, 6>(a, p, grid, s);
     }
 }
 
@@ -770,7 +973,7 @@ size_t sprk_conv2d_fwd_ws_bytes(const sprk_conv_geom *g) {
     if (!g) return 0;
     FwdPlan p;
     if (!plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, &p)) return 0;
-    return (size_t)p.rows * p.NPadTotal * sizeof(float);
+    return p.wsBytes;
 }
 
 int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, const sprk_conv_geom *g,
@@ -791,17 +994,15 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
     FwdPlan p;
     SPRK_REQUIRE(plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, &p),
                  "conv2d_fwd: geometry does not fit LDS");
-    const size_t need = (size_t)p.rows * p.NPadTotal * sizeof(float);
-    if (ws_bytes < need || !ws) {
-        sprk::set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
+    if (ws_bytes < p.wsBytes || !ws) {
+        sprk::set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, p.wsBytes);
         return SPRK_EWORKSPACE;
     }
-    float *wT = (float *)ws;
-    hipLaunchKernelGGL(weight_transform_kernel, dim3(sprk::ew_blocks((long)p.rows * p.NPadTotal)), dim3(256), 0, s, w,
-                       wT, g->Cout, g->C1 + g->C2, g->KH * g->KW, 0, p.CK, p.R4, p.rows, p.NPadTotal);
-    if (int rc = sprk::check_launch("weight_transform")) return rc;
+    float *wsf = (float *)ws;
+    if (int rc = transform_weights(w, wsf, g->Cout, g->C1 + g->C2, g->KH * g->KW, 0, p, s)) return rc;
     ConvArgs a{};
-    a.x = x; a.x2 = x2; a.wT = wT; a.bias = ep->bias; a.scale = ep->scale; a.shift = ep->shift; a.res = ep->res;
+    a.x = x; a.x2 = x2; a.zeros = wsf; a.wT = wsf + kZeroFloats;
+    a.bias = ep->bias; a.scale = ep->scale; a.shift = ep->shift; a.res = ep->res;
     a.y = y;
     a.N = g->N; a.C1 = g->C1; a.C2 = g->C2; a.Hin = g->Hin; a.Win = g->Win; a.up1 = g->up1;
     a.H1 = g->up1 ? g->Hin / 2 : g->Hin;
@@ -814,7 +1015,7 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
     a.vec4 = (g->Wout % 4 == 0) && (p.lgTC >= 2) && (((uintptr_t)y & 15) == 0);
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * g->KH * g->KW;
     sprk::prof_begin(0, flops, s);
-    launch_fwd(a, p, s);
+    if (int rc = launch_fwd(a, p, s)) return rc;
     sprk::prof_end(0, s);
     return sprk::check_launch("conv_mfma");
 }
@@ -823,7 +1024,7 @@ size_t sprk_conv2d_bwd_data_ws_bytes(const sprk_conv_geom *g) {
     if (!g || g->stride != 1) return 0;
     FwdPlan p;
     if (!plan_fwd(g->N, g->Cout, g->C1 + g->C2, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, &p)) return 0;
-    return (size_t)p.rows * p.NPadTotal * sizeof(float);
+    return p.wsBytes;
 }
 
 int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk_conv_geom *g, void *ws,
@@ -843,17 +1044,14 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
     FwdPlan p;
     SPRK_REQUIRE(plan_fwd(g->N, g->Cout, Cin, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, &p),
                  "conv2d_bwd_data: geometry does not fit LDS");
-    const size_t need = (size_t)p.rows * p.NPadTotal * sizeof(float);
-    if (ws_bytes < need || !ws) {
-        sprk::set_error("conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
+    if (ws_bytes < p.wsBytes || !ws) {
+        sprk::set_error("conv2d_bwd_data: workspace %zu < %zu", ws_bytes, p.wsBytes);
         return SPRK_EWORKSPACE;
     }
-    float *wT = (float *)ws;
-    hipLaunchKernelGGL(weight_transform_kernel, dim3(sprk::ew_blocks((long)p.rows * p.NPadTotal)), dim3(256), 0, s, w,
-                       wT, g->Cout, Cin, g->KH * g->KW, 1, p.CK, p.R4, p.rows, p.NPadTotal);
-    if (int rc = sprk::check_launch("weight_transform")) return rc;
+    float *wsf = (float *)ws;
+    if (int rc = transform_weights(w, wsf, g->Cout, Cin, g->KH * g->KW, 1, p, s)) return rc;
     ConvArgs a{};
-    a.x = gy; a.x2 = nullptr; a.wT = wT; a.y = gin;
+    a.x = gy; a.x2 = nullptr; a.zeros = wsf; a.wT = wsf + kZeroFloats; a.y = gin;
     a.N = g->N; a.C1 = g->Cout; a.C2 = 0; a.Hin = g->Hout; a.Win = g->Wout; a.up1 = 0;
     a.H1 = g->Hout; a.W1 = g->Wout;
     a.Cout = Cin; a.Hout = g->Hin; a.Wout = g->Win;
@@ -865,7 +1063,7 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
     a.vec4 = (g->Win % 4 == 0) && (p.lgTC >= 2) && (((uintptr_t)gin & 15) == 0);
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * g->KH * g->KW;
     sprk::prof_begin(0, flops, s);
-    launch_fwd(a, p, s);
+    if (int rc = launch_fwd(a, p, s)) return rc;
     sprk::prof_end(0, s);
     return sprk::check_launch("conv_mfma(bwd_data)");
 }
@@ -874,7 +1072,7 @@ size_t sprk_conv2d_bwd_weight_ws_bytes(const sprk_conv_geom *g) {
     if (!g) return 0;
     WgPlan p;
     if (!plan_wgrad(g, &p)) return 0;
-    return (size_t)p.groups * g->Cout * (g->C1 + g->C2) * g->KH * g->KW * sizeof(float);
+    return p.wsBytes;
 }
 
 int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, float *gw, const sprk_conv_geom *g,
@@ -892,39 +1090,50 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
         hipLaunchKernelGGL(conv_bwd_weight_direct_kernel, dim3(g->Cout * Cin), dim3(256), 0, s, a);
         return sprk::check_launch("conv_bwd_weight_direct");
     }
-    const long nW = (long)g->Cout * Cin * g->KH * g->KW;
-    const size_t need = (size_t)p.groups * nW * sizeof(float);
-    if (ws_bytes < need || !ws) {
-        sprk::set_error("conv2d_bwd_weight: workspace %zu < %zu", ws_bytes, need);
+    if (ws_bytes < p.wsBytes || !ws) {
+        sprk::set_error("conv2d_bwd_weight: workspace %zu < %zu", ws_bytes, p.wsBytes);
         return SPRK_EWORKSPACE;
     }
+    float *wsf = (float *)ws;
+    if (hipMemsetAsync(wsf, 0, kZeroFloats * sizeof(float), s) != hipSuccess) {
+        sprk::set_error("conv2d_bwd_weight: memset failed");
+        return SPRK_ELAUNCH;
+    }
     WgArgs a{};
-    a.x = x; a.x2 = x2; a.gy = gy; a.partial = (float *)ws;
+    a.x = x; a.x2 = x2; a.gy = gy; a.zeros = wsf; a.partial = wsf + kZeroFloats;
     a.N = g->N; a.C1 = g->C1; a.C2 = g->C2; a.Hin = g->Hin; a.Win = g->Win; a.up1 = g->up1;
     a.H1 = g->up1 ? g->Hin / 2 : g->Hin;
     a.W1 = g->up1 ? g->Win / 2 : g->Win;
-    a.Cout = g->Cout; a.Hout = g->Hout; a.Wout = g->Wout;
+    a.Cout = g->Cout; a.CoutP = p.CoutP; a.Hout = g->Hout; a.Wout = g->Wout;
     a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.dil = g->dil; a.padT = g->pad_top; a.padL = g->pad_left;
     a.lgTC = p.lgTC; a.lgTR = p.lgTR; a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.nTiles = p.nTiles;
     a.tilesPerGroup = p.tilesPerGroup;
     a.CKW = p.CKW; a.ioffN = p.ioffN;
-    a.inRows = p.inRows; a.inCols = p.inCols; a.pitch = p.pitch; a.cplane = p.cplane; a.gstride = p.gstride;
+    a.inRows = p.inRows; a.inCols = p.inCols; a.pitch = p.pitch; a.cplane = p.cplane;
     a.invImg = 1.0f / (float)(p.inRows * p.inCols);
     a.invInCols = 1.0f / (float)p.inCols;
-    a.invPlane = 1.0f / (float)((64 >> (p.lgTC + p.lgTR)) * p.inRows * p.inCols);
+    a.xrow = p.xrow;
+    a.g4 = (p.lgTC >= 2 && (g->Wout % 4) == 0 && ((uintptr_t)gy & 15) == 0) ? 1 : 0;
+    if (a.xrow && (((uintptr_t)x & 15) != 0)) {
+        sprk::set_error("conv2d_bwd_weight: x must be 16-byte aligned");
+        return SPRK_EINVAL;
+    }
     dim3 grid(p.groups, p.nChunks, p.nblkN);
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * g->KH * g->KW;
     sprk::prof_begin(1, flops, s);
+    int rc;
     switch (p.IT) {
-        case 1: launch_wg_nt<1>(a, p, grid, s); break;
-        case 2: launch_wg_nt<2>(a, p, grid, s); break;
-        case 3: launch_wg_nt<3>(a, p, grid, s); break;
-        default: launch_wg_nt<5>(a, p, grid, s); break;
+        case 1: rc = launch_wg_nt<1>(a, p, grid, s); break;
+        case 2: rc = launch_wg_nt<2>(a, p, grid, s); break;
+        case 3: rc = launch_wg_nt<3>(a, p, grid, s); break;
+        default: rc = launch_wg_nt<5>(a, p, grid, s); break;
     }
+    if (rc) return rc;
     sprk::prof_end(1, s);
-    if (int rc = sprk::check_launch("conv_wgrad_mfma")) return rc;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(sprk::ew_blocks(nW)), dim3(256), 0, s, (const float *)ws, gw, nW,
-                       p.groups);
+    if (int rc2 = sprk::check_launch("conv_wgrad_mfma")) return rc2;
+    const int K = Cin * g->KH * g->KW;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(sprk::ew_blocks((long)K * p.CoutP)), dim3(256), 0, s,
+                       (const float *)(wsf + kZeroFloats), gw, K, g->Cout, p.CoutP, p.groups);
     return sprk::check_launch("reduce_partials");
 }
 
