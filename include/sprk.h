@@ -54,11 +54,15 @@ typedef struct sprk_conv_geom {
  *   v = acc (+ res[n,co,oy+res_off,ox+res_off])            res: [N,Cout,res_h,res_w]
  *   v = scale ? v*scale[co] + shift[co] : v + (bias ? bias[co] : 0)
  *   v = act(v)
- * (residual add + eval-mode BatchNorm affine + ReLU of ResidA, feature_extractor.py:384-416). */
+ * (residual add + eval-mode BatchNorm affine + ReLU of ResidA, feature_extractor.py:384-416).
+ * up2 != 0: y is [N,Cout,2*Hout,2*Wout] and every value is stored to its 2x2 block — the
+ * nn.Upsample(scale_factor=2, mode="nearest") that follows the conv in the reference's decoder
+ * blocks (joint_network_v2.py:69-97), fused into the store. */
 typedef struct sprk_conv_epilogue {
     const float *bias, *scale, *shift, *res;
     int32_t res_h, res_w, res_off;
     int32_t act;
+    int32_t up2;
 } sprk_conv_epilogue;
 
 const char *sprk_last_error(void);
@@ -84,12 +88,14 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
 size_t sprk_conv2d_bwd_weight_ws_bytes(const sprk_conv_geom *g);
 int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, float *gw,
                            const sprk_conv_geom *g, void *ws, size_t ws_bytes, void *stream);
-/* gpre = gy * act'(y) where y is the saved POST-activation output (gpre may alias gy; with
- * act == NONE nothing is written to gpre and it may be NULL); if gbias != NULL also
- * gbias[c] = sum over n,h,w of gpre (conv bias gradient).  ws: C*nsplit floats. */
+/* gpre[N,C,H,W] = gy * act'(y) where y is the saved POST-activation output (gpre may alias gy;
+ * with act == NONE and up2 == 0 nothing is written to gpre and it may be NULL); if gbias != NULL
+ * also gbias[c] = sum over n,h,w of gpre (conv bias gradient).  up2 != 0: gy and y are the
+ * [N,C,2H,2W] tensors of a conv with the fused-upsample epilogue; gy is first summed over each
+ * 2x2 block (backward of nn.Upsample).  ws: C*nsplit floats. */
 size_t sprk_act_bwd_ws_bytes(int N, int C, int HW);
 int sprk_act_bwd(const float *gy, const float *y, float *gpre, float *gbias, int act,
-                 int N, int C, int HW, void *ws, size_t ws_bytes, void *stream);
+                 int N, int C, int H, int W, int up2, void *ws, size_t ws_bytes, void *stream);
 /* split the gradient of a fused (upsample2(a) ++ b) conv input: ga[N,C1,H/2,W/2] = 2x2 sums
  * of gin[:, :C1], gb[N,C2,H,W] = gin[:, C1:].  (autograd of nn.Upsample + torch.cat) */
 int sprk_concat_up_bwd(const float *gin, float *ga, float *gb, int N, int C1, int C2, int H, int W,

@@ -23,7 +23,7 @@ class ConvGeom(ctypes.Structure):
 class ConvEpilogue(ctypes.Structure):
     _fields_ = [("bias", c_vp), ("scale", c_vp), ("shift", c_vp), ("res", c_vp),
                 ("res_h", ctypes.c_int32), ("res_w", ctypes.c_int32), ("res_off", ctypes.c_int32),
-                ("act", ctypes.c_int32)]
+                ("act", ctypes.c_int32), ("up2", ctypes.c_int32)]
 
 
 _SIGS = {
@@ -38,7 +38,7 @@ _SIGS = {
     "sprk_conv2d_bwd_weight_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_bwd_weight": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
     "sprk_act_bwd_ws_bytes": (c_sz, [c_i, c_i, c_i]),
-    "sprk_act_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "sprk_act_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "sprk_concat_up_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "sprk_shift_maxpool2_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),
     "sprk_shift_maxpool2_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),

@@ -18,6 +18,8 @@
 // cross-check (sprk_set_naive).
 #include "common.h"
 
+#include <cstdlib>
+
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 namespace {
@@ -90,52 +92,86 @@ __device__ __forceinline__ void dma16(const float *src, float *lds_wave_base) {
     __builtin_amdgcn_global_load_lds(src, (lds_void *)lds_wave_base, 16, 0, 0);
 }
 
-// Source of the (virtual) conv input: channel concat of x (optionally 2x nearest-upsampled on
-// the fly) and x2, zero outside the image.
+// LDS image of an input tile: [channel][image][row][col], row pitch `pitch` (a multiple of 4), channel
+// stride `cplane`; column j of the image is input column ixa + j where ixa = ix0 - colOff is a multiple
+// of 4, so every 4-column chunk of the image is a 16-byte aligned run of one global row that lies
+// entirely inside or entirely outside the image (Win % 4 == 0).  The [image][row][col] plane is
+// contiguous, i.e. lane-linear for LDS-DMA: 64 chunks (16 B per lane) or 64 elements (4 B per lane,
+// the fallback for upsampled-on-load or unaligned sources) per wave instruction; lanes outside the
+// image read the zero block.
+struct PlaneGeom {
+    int NI, inRows, pitch, colOff, cplane;
+    float invImg, invPitch;
+    int deal;  // 1: deal (group, channel) items round-robin to waves; 0: whole groups per wave
+};
+
+// nch channel planes from one source tensor: `base` points at channel 0 of image 0 of the staged
+// channel range; imgStride / cs are the image / channel strides in floats; (Hs, Ws) the source plane
+// size; up: source is half resolution, nearest-upsampled on load.
+__device__ __forceinline__ void stage_planes(float *dst, const float *base, long imgStride, long cs, int nch, int N,
+                                             int Hin, int Win, int Ws, int up, int vec, const float *zeros,
+                                             const PlaneGeom &g, int n0, int iy0, int ixa, int lw, int lane) {
+    const int imgElems = g.inRows * g.pitch;
+    const int planeElems = g.NI * imgElems;
+    const int per = vec ? 256 : 64;
+    const int nGroups = (planeElems + per - 1) / per;
+    // work items (group, channel) are dealt round-robin to the issuing waves: every wave walks all
+    // groups but only every kIssuers-th channel, so the issue load is even whatever nGroups is
+    const int gstart = g.deal ? 0 : lw, gstep = g.deal ? 1 : kIssuers, cstep = g.deal ? kIssuers : 1;
+    for (int gi = gstart; gi < nGroups; gi += gstep) {
+        const int e = vec ? gi * 256 + lane * 4 : gi * 64 + lane;
+        const int il = fast_div(e, g.invImg);
+        const int rem = e - il * imgElems;
+        const int r = fast_div(rem, g.invPitch);
+        const int j = rem - r * g.pitch;
+        const int n = n0 + il, iy = iy0 + r, ix = ixa + j;
+        const bool inb = e < planeElems;
+        const bool ok = inb && n < N && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        const int cl0 = g.deal ? (lw + kIssuers - (gi % kIssuers)) % kIssuers : 0;
+        const float *p = base + (long)n * imgStride + (up ? (long)(iy >> 1) * Ws + (ix >> 1) : (long)iy * Ws + ix) +
+                         (long)cl0 * cs;
+        long step = (long)cstep * cs;
+        if (!ok) {  // lanes outside the image read the zero block
+            p = zeros + lane * 4;
+            step = 0;
+        }
+        float *d = dst + gi * per + cl0 * g.cplane;
+        for (int cl = cl0; cl < nch; cl += cstep) {
+            if (inb) {
+                if (vec)
+                    dma16(p, d);
+                else
+                    dma4(p, d);
+            }
+            p += step;
+            d += cstep * g.cplane;
+        }
+    }
+}
+
+// Source of the (virtual) conv input: channel concat of x (optionally 2x nearest-upsampled on the
+// fly) and x2, zero outside the image.
 struct TileSrc {
     const float *x, *x2, *zeros;
     int N, C1, C2, Hin, Win, up1, H1, W1;
+    int vec1, vec2;  // 16-byte DMA allowed for source 1 / source 2
 };
 
-// Stage `cke` channels [c0, c0+cke) of the input tile whose top-left input coordinate is
-// (iy0, ix0), first image n0, into LDS laid out [cl][il][row][col] (row pitch = inCols, channel
-// stride cplane).  The [il][row][col] plane is contiguous, so 64 consecutive plane elements are
-// one wave-wide DMA; lanes outside the image read the zero block instead.
-// vec4: plane rows are 16-byte aligned runs in global memory (1x1 convs): 256 elements per DMA.
-__device__ __forceinline__ void stage_input_dma(float *in_lds, const TileSrc &s, int n0, int iy0, int ix0, int NI,
-                                                int inRows, int inCols, int cplane, float invImg, float invInCols,
-                                                int c0, int cke, int lw, int lane, int vec4) {
-    const int imgElems = inRows * inCols;
-    const int planeElems = NI * imgElems;
-    const long cs1 = (long)s.H1 * s.W1, cs2 = (long)s.Hin * s.Win;
-    const int per = vec4 ? 256 : 64;
-    const int nGroups = (planeElems + per - 1) / per;
-    for (int gi = lw; gi < nGroups; gi += kIssuers) {
-        const int e = vec4 ? gi * 256 + lane * 4 : gi * 64 + lane;
-        const int il = fast_div(e, invImg);
-        const int rem = e - il * imgElems;
-        const int r = fast_div(rem, invInCols);
-        const int col = rem - r * inCols;
-        const int n = n0 + il, iy = iy0 + r, ix = ix0 + col;
-        const bool inb = e < planeElems;
-        const bool ok = inb && n < s.N && (unsigned)iy < (unsigned)s.Hin && (unsigned)ix < (unsigned)s.Win;
-        const float *p1 = s.x + ((long)n * s.C1 + c0) * cs1 +
-                          (s.up1 ? (long)(iy >> 1) * s.W1 + (ix >> 1) : (long)iy * s.W1 + ix);
-        const float *p2 = s.x2 + ((long)n * s.C2 + (c0 - s.C1)) * cs2 + (long)iy * s.Win + ix;
-        float *dst = in_lds + gi * per;
-        for (int cl = 0; cl < cke; ++cl) {
-            const float *src = (c0 + cl < s.C1) ? p1 : p2;
-            if (!ok) src = s.zeros + lane * 4;
-            if (inb) {
-                if (vec4)
-                    dma16(src, dst);
-                else
-                    dma4(src, dst);
-            }
-            p1 += cs1;
-            p2 += cs2;
-            dst += cplane;
-        }
+// channels [c0, c0+cke) of the concatenated input
+__device__ __forceinline__ void stage_input_dma(float *in_lds, const TileSrc &s, const PlaneGeom &g, int n0, int iy0,
+                                                int ix0, int c0, int cke, int lw, int lane) {
+    const int ixa = ix0 - g.colOff;
+    const int n1 = max(0, min(c0 + cke, s.C1) - c0);  // channels taken from x
+    if (n1 > 0) {
+        const long cs1 = (long)s.H1 * s.W1;
+        stage_planes(in_lds, s.x + (long)c0 * cs1, (long)s.C1 * cs1, cs1, n1, s.N, s.Hin, s.Win, s.W1, s.up1, s.vec1,
+                     s.zeros, g, n0, iy0, ixa, lw, lane);
+    }
+    if (n1 < cke) {
+        const long cs2 = (long)s.Hin * s.Win;
+        const int cb = max(c0, s.C1) - s.C1;
+        stage_planes(in_lds + n1 * g.cplane, s.x2 + (long)cb * cs2, (long)s.C2 * cs2, cs2, cke - n1, s.N, s.Hin, s.Win,
+                     s.Win, 0, s.vec2, s.zeros, g, n0, iy0, ixa, lw, lane);
     }
 }
 
@@ -152,15 +188,79 @@ struct ConvArgs {
     int lgTC, lgTR;
     int tilesX, tilesY;
     int CK, R4, rows;
-    int inRows, inCols, pitch, cplane;
+    int inRows, inCols, pitch, cplane, colOff;
     int ldw;
     int resH, resW, resOff;
-    int vec4, in4;
-    float invImg, invInCols;
+    int vec4, vec1, vec2, up2, deal;
+    float invImg, invPitch;
 };
 
+// Epilogue of one 16x16 accumulator tile: this lane holds output channel `co` for the 4 consecutive
+// tile pixels pb..pb+3.  (+ residual) -> affine / bias -> activation -> store (optionally 2x upsampled).
+__device__ __forceinline__ void store_tile(const ConvArgs &a, const f32x4 c, int pb, int co, int n0, int oy0, int ox0,
+                                           int lgT, int TRm, int TCm) {
+    if (co >= a.Cout) return;
+    const long planeO = (long)a.Hout * a.Wout;
+    float sc = 1.f, sh = 0.f;
+    if (a.scale) {
+        sc = a.scale[co];
+        sh = a.shift[co];
+    } else if (a.bias) {
+        sh = a.bias[co];
+    }
+    const float cv[4] = {c[0], c[1], c[2], c[3]};
+    float v[4];
+    int n_[4], oy_[4], ox_[4];
+    bool ok_[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = pb + j;
+        const int il = p >> lgT, r = (p >> a.lgTC) & TRm, cc = p & TCm;
+        n_[j] = n0 + il;
+        oy_[j] = oy0 + r;
+        ox_[j] = ox0 + cc;
+        ok_[j] = n_[j] < a.N && oy_[j] < a.Hout && ox_[j] < a.Wout;
+        float t = cv[j];
+        if (a.res && ok_[j])
+            t += a.res[(((long)n_[j] * a.Cout + co) * a.resH + oy_[j] + a.resOff) * a.resW + ox_[j] + a.resOff];
+        v[j] = apply_act(t * sc + sh, a.act);
+    }
+    if (a.up2) {
+        // fused nn.Upsample(2, nearest): every value is written to its 2x2 block of y[N,Cout,2H,2W]
+        const long W2 = 2L * a.Wout;
+        if (a.vec4) {
+            if (ok_[0]) {
+                float *q = a.y + ((long)n_[0] * a.Cout + co) * planeO * 4 + (long)(2 * oy_[0]) * W2 + 2 * ox_[0];
+                const float4 lo = make_float4(v[0], v[0], v[1], v[1]), hi = make_float4(v[2], v[2], v[3], v[3]);
+                *reinterpret_cast<float4 *>(q) = lo;
+                *reinterpret_cast<float4 *>(q + 4) = hi;
+                *reinterpret_cast<float4 *>(q + W2) = lo;
+                *reinterpret_cast<float4 *>(q + W2 + 4) = hi;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ok_[j]) {
+                    float *q = a.y + ((long)n_[j] * a.Cout + co) * planeO * 4 + (long)(2 * oy_[j]) * W2 + 2 * ox_[j];
+                    q[0] = v[j];
+                    q[1] = v[j];
+                    q[W2] = v[j];
+                    q[W2 + 1] = v[j];
+                }
+        }
+    } else if (a.vec4) {
+        if (ok_[0])
+            *reinterpret_cast<float4 *>(a.y + ((long)n_[0] * a.Cout + co) * planeO + (long)oy_[0] * a.Wout + ox_[0]) =
+                make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ok_[j]) a.y[((long)n_[j] * a.Cout + co) * planeO + (long)oy_[j] * a.Wout + ox_[j]] = v[j];
+    }
+}
+
 template <int MT, int NT>
-__global__ __launch_bounds__(kBlock) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) {
     // LDS: koff[2][R4] | stage 0: input[CK*cplane] weights[R4*ldw] | stage 1: ...
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int stageFloats = a.CK * a.cplane + a.R4 * a.ldw;
@@ -192,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void conv_mfma_kernel(const ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt) {
         const int p = ((wave & 3) * MT + mt) * 16 + l15;
         const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
-        pixbase[mt] = (il * a.inRows + r * a.stride) * a.pitch + c * a.stride;
+        pixbase[mt] = (il * a.inRows + r * a.stride) * a.pitch + c * a.stride + a.colOff;
     }
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -200,7 +300,8 @@ __global__ __launch_bounds__(kBlock) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1};
+    const TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1, a.vec1, a.vec2};
+    const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal};
     const float *wslab = a.wT + (long)nb * a.rows * a.ldw;
     int tab_cke0 = -1, tab_cke1 = -1;
 
@@ -225,8 +326,7 @@ __global__ __launch_bounds__(kBlock) void conv_mfma_kernel(const ConvArgs a) {
         }
         float *in_lds = stage_base + b * stageFloats;
         float *w_lds = in_lds + a.CK * a.cplane;
-        stage_input_dma(in_lds, src, n0, iy0, ix0, NI, a.inRows, a.inCols, a.cplane, a.invImg, a.invInCols, c0, cke,
-                        lw, lane, a.in4);
+        stage_input_dma(in_lds, src, pg, n0, iy0, ix0, c0, cke, lw, lane);
         const float *wsrc = wslab + (long)(c0 / a.CK) * a.R4 * a.ldw;
         const int total4 = (kchunk * a.ldw) >> 2;
         for (int gi = lw; gi * 64 < total4; gi += kIssuers) {
@@ -280,49 +380,13 @@ __global__ __launch_bounds__(kBlock) void conv_mfma_kernel(const ConvArgs a) {
 
     if (!compute) return;  // no barrier below
     // epilogue: D layout col(n) = lane&15, row(m) = (lane>>4)*4 + reg
-    const long planeO = (long)a.Hout * a.Wout;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int pb = (wave * MT + mt) * 16 + lq * 4;
-        int n_[4], oy_[4], ox_[4];
-        bool ok_[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int p = pb + j;
-            const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
-            n_[j] = n0 + il;
-            oy_[j] = oy0 + r;
-            ox_[j] = ox0 + c;
-            ok_[j] = n_[j] < a.N && oy_[j] < a.Hout && ox_[j] < a.Wout;
-        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int co = nb * (NT * 16) + nt * 16 + l15;
-            if (co >= a.Cout) continue;
-            float sc = 1.f, sh = 0.f;
-            if (a.scale) {
-                sc = a.scale[co];
-                sh = a.shift[co];
-            } else if (a.bias) {
-                sh = a.bias[co];
-            }
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float t = acc[mt][nt][j];
-                if (a.res && ok_[j])
-                    t += a.res[(((long)n_[j] * a.Cout + co) * a.resH + oy_[j] + a.resOff) * a.resW + ox_[j] + a.resOff];
-                v[j] = apply_act(t * sc + sh, a.act);
-            }
-            if (a.vec4) {
-                if (ok_[0])
-                    *reinterpret_cast<float4 *>(a.y + ((long)n_[0] * a.Cout + co) * planeO + (long)oy_[0] * a.Wout + ox_[0]) =
-                        make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (ok_[j]) a.y[((long)n_[j] * a.Cout + co) * planeO + (long)oy_[j] * a.Wout + ox_[j]] = v[j];
-            }
+            store_tile(a, acc[mt][nt], pb, co, n0, oy0, ox0, lgT, TRm, TCm);
         }
     }
 }
@@ -344,9 +408,9 @@ struct WgArgs {
     int tilesX, tilesY, nTiles, tilesPerGroup;
     int CKW;                 // input channels per blockIdx.y
     int ioffN;               // ints reserved for the k-row offset table
-    int inRows, inCols, pitch, cplane;
-    int xrow, g4;
-    float invImg, invInCols;
+    int inRows, inCols, pitch, cplane, colOff;
+    int xrow, g4, vec1, vec2, deal;
+    float invImg, invPitch;
 };
 
 // one 64-pixel tile: 16 k-steps of MFMAs on NIT k-tiles x NT cout-tiles (branch free, fully unrolled
@@ -409,10 +473,11 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_mfma_kernel(const WgArgs a)
     }
     if (tid < 64) {
         const int il = tid >> lgT, r = (tid >> a.lgTC) & TRm, c = tid & TCm;
-        pixoff[tid] = (il * a.inRows + r * a.stride) * a.pitch + c * a.stride;
+        pixoff[tid] = (il * a.inRows + r * a.stride) * a.pitch + c * a.stride + a.colOff;
     }
 
-    TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1};
+    const TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1, a.vec1, a.vec2};
+    const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal};
     // rows of 64 pixels, 16-byte chunks XOR-swizzled by (row & 7): LDS chunk (row, qs) <- pixels
     // 4q..4q+3, q = qs ^ (row & 7).  base: tensor [N][C][H*W]; row r is channel ch0 + r.
     auto stage_rows16 = [&](float *dst, const float *base, int C, long plane, int W, int H, int ch0, int nrows,
@@ -440,8 +505,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_mfma_kernel(const WgArgs a)
         if (a.xrow)
             stage_rows16(x_lds, a.x, a.C1, planeI, a.Win, a.Hin, c0, cke, Cin, n0, oy0, ox0);
         else
-            stage_input_dma(x_lds, src, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, NI, a.inRows, a.inCols,
-                            a.cplane, a.invImg, a.invInCols, c0, cke, lw, lane, 0);
+            stage_input_dma(x_lds, src, pg, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, c0, cke, lw, lane);
         if (a.g4) {
             stage_rows16(g_lds, a.gy, a.Cout, planeO, a.Wout, a.Hout, co0, NT * 16, a.Cout, n0, oy0, ox0);
         } else {
@@ -583,7 +647,16 @@ __global__ void conv_fwd_direct_kernel(const DirectArgs a) {
             s = s * a.ep.scale[co] + a.ep.shift[co];
         else if (a.ep.bias)
             s += a.ep.bias[co];
-        a.y[e] = apply_act(s, a.ep.act);
+        const float v = apply_act(s, a.ep.act);
+        if (a.ep.up2) {
+            float *q = a.y + (((long)n * g.Cout + co) * (2 * g.Hout) + 2 * oy) * (2L * g.Wout) + 2 * ox;
+            q[0] = v;
+            q[1] = v;
+            q[2L * g.Wout] = v;
+            q[2L * g.Wout + 1] = v;
+        } else {
+            a.y[e] = v;
+        }
     }
 }
 
@@ -651,20 +724,31 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_direct_kernel(const Direc
 // activation backward (+ bias gradient) and concat/upsample gradient split
 // ------------------------------------------------------------------------------------------
 // grid (C, nsplit): block (c, s) walks images n = s, s+nsplit, ... of channel c.
+// up2: g and y are the 2x upsampled tensors [N,C,2H,2W] written by a conv with the fused upsample
+// epilogue; the incoming gradient is first summed over each 2x2 block (backward of nn.Upsample).
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const float *__restrict__ y, float *gpre,
                                                       float *__restrict__ partial, int act, int N, int C, int HW,
-                                                      int nsplit) {
+                                                      int W, int up2, int nsplit) {
     const int c = blockIdx.x, s = blockIdx.y;
     float sum = 0.f;
     for (int n = s; n < N; n += nsplit) {
         const long base = ((long)n * C + c) * HW;
         for (int i = threadIdx.x; i < HW; i += 256) {
-            float v = g[base + i];
+            float v, yv = 0.f;
+            if (up2) {
+                const int oy = i / W, ox = i - oy * W;
+                const long q = base * 4 + (long)(2 * oy) * (2 * W) + 2 * ox;
+                v = (g[q] + g[q + 1]) + (g[q + 2 * W] + g[q + 2 * W + 1]);
+                if (act != SPRK_ACT_NONE) yv = y[q];
+            } else {
+                v = g[base + i];
+                if (act != SPRK_ACT_NONE) yv = y[base + i];
+            }
             if (act == SPRK_ACT_LEAKY)
-                v = y[base + i] > 0.f ? v : v * kLeak;
+                v = yv > 0.f ? v : v * kLeak;
             else if (act == SPRK_ACT_RELU)
-                v = y[base + i] > 0.f ? v : 0.f;
-            if (act != SPRK_ACT_NONE) gpre[base + i] = v;
+                v = yv > 0.f ? v : 0.f;
+            if (act != SPRK_ACT_NONE || up2) gpre[base + i] = v;
             sum += v;
         }
     }
@@ -728,7 +812,7 @@ constexpr size_t kLdsLimit = 160 * 1024;
 struct FwdPlan {
     int MT, NT, lgTC, lgTR, tilesX, tilesY, imgGroups, nblkN;
     int CK, R4, rows;
-    int inRows, inCols, pitch, cplane, ldw, NI;
+    int inRows, inCols, pitch, cplane, colOff, ldw, NI;
     size_t ldsBytes, wsBytes;
 };
 
@@ -751,7 +835,7 @@ int pick_nt(int ntile) {
 }
 
 // Ck: channels along GEMM-k; Nn: GEMM-n extent; output spatial dims Ho x Wo over Nimg images
-bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stride, int dil, FwdPlan *p) {
+bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stride, int dil, int padL, FwdPlan *p) {
     const int KHW = KH * KW;
     const int ntile = sprk::cdiv(Nn, 16);
     int NT = pick_nt(ntile);
@@ -774,7 +858,9 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
         p->nblkN = sprk::cdiv(ntile, nt);
         p->inRows = (TR - 1) * stride + (KH - 1) * dil + 1;
         p->inCols = (TC - 1) * stride + (KW - 1) * dil + 1;
-        p->pitch = p->inCols;  // the plane must be contiguous for the LDS-DMA image
+        // image column 0 sits on a 16-byte boundary of the global rows (tile origins are multiples of 4)
+        p->colOff = ((TC * stride) % 4 == 0) ? (((-padL) % 4) + 4) % 4 : 0;
+        p->pitch = sprk::roundup(p->colOff + p->inCols, 4);
         p->cplane = pad_to_residue(NI * p->inRows * p->pitch, 16);
         return (long)p->imgGroups * p->tilesX * p->tilesY * p->nblkN;
     };
@@ -795,6 +881,8 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
     };
     int CK = std::max(1, std::min(Ck, KHW == 1 ? 16 : std::max(1, 36 / KHW)));
     while (CK > 1 && lds(CK) > 52 * 1024) CK >>= 1;
+    // small tiles: longer K-chunks (fewer barriers) while the stages stay small
+    while (CK * 2 <= Ck && CK * 2 * KHW <= 288 && lds(CK * 2) <= 24 * 1024) CK *= 2;
     if (lds(CK) > kLdsLimit) return false;
     p->CK = CK;
     p->R4 = sprk::roundup(CK * KHW, 4);
@@ -843,6 +931,16 @@ int launch_fwd(const ConvArgs &a, const FwdPlan &p, hipStream_t s) {
     }
 }
 
+int dbg_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+bool aligned16(const void *p) {
+    static const bool novec = getenv("SPRK_NOVEC") != nullptr;  // debug: force the 4-byte DMA path
+    return !novec && (((uintptr_t)p) & 15) == 0;
+}
+
 void fill_args(ConvArgs &a, const FwdPlan &p) {
     a.lgTC = p.lgTC;
     a.lgTR = p.lgTR;
@@ -855,14 +953,15 @@ void fill_args(ConvArgs &a, const FwdPlan &p) {
     a.inCols = p.inCols;
     a.pitch = p.pitch;
     a.cplane = p.cplane;
+    a.colOff = p.colOff;
     a.ldw = p.ldw;
-    a.invImg = 1.0f / (float)(p.inRows * p.inCols);
-    a.invInCols = 1.0f / (float)p.inCols;
-    // 16-byte DMA of the input plane: no halo columns and 4-pixel runs aligned in global memory
-    a.in4 = (a.KW == 1 && a.padL == 0 && a.stride == 1 && !a.up1 && (a.Win % 4) == 0 && p.lgTC >= 2 &&
-             (((uintptr_t)a.x | (uintptr_t)a.x2) & 15) == 0)
-                ? 1
-                : 0;
+    a.invImg = 1.0f / (float)(p.inRows * p.pitch);
+    a.invPitch = 1.0f / (float)p.pitch;
+    // 16-byte DMA: tile origins on 4-column boundaries, rows 16-byte aligned, source at full resolution
+    const bool geo = ((1 << p.lgTC) * a.stride) % 4 == 0 && (a.Win % 4) == 0;
+    a.vec1 = (geo && !a.up1 && aligned16(a.x)) ? 1 : 0;
+    a.vec2 = (geo && a.x2 && aligned16(a.x2)) ? 1 : 0;
+    a.deal = dbg_int("SPRK_DEAL", 1);
 }
 
 int transform_weights(const float *w, float *ws, int Cout, int Cin, int KHW, int mode, const FwdPlan &p,
@@ -886,7 +985,7 @@ int check_geom(const sprk_conv_geom *g) {
 struct WgPlan {
     int IT, NT, lgTC, lgTR, tilesX, tilesY, nTiles, tilesPerGroup, groups;
     int CKW, nChunks, nblkN, ioffN, CoutP;
-    int inRows, inCols, pitch, cplane, xrow;
+    int inRows, inCols, pitch, cplane, colOff, xrow;
     size_t ldsBytes, wsBytes;
 };
 
@@ -909,15 +1008,22 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     p->nTiles = sprk::cdiv(g->N, NI) * p->tilesX * p->tilesY;
     p->inRows = (TR - 1) * g->stride + (g->KH - 1) * g->dil + 1;
     p->inCols = (TC - 1) * g->stride + (g->KW - 1) * g->dil + 1;
-    p->pitch = p->inCols;
-    p->cplane = pad_to_residue(NI * p->inRows * p->pitch, 2);
+    p->colOff = ((TC * g->stride) % 4 == 0) ? (((-g->pad_left) % 4) + 4) % 4 : 0;
+    p->pitch = sprk::roundup(p->colOff + p->inCols, 4);
+    // channel stride: 16-byte DMA needs a multiple of 4 floats (then 16 channels x 2 pixels of one A read
+    // share banks pairwise: 2-way); the 4-byte DMA fallback can use the conflict-free stride = 2 (mod 32)
+    const bool vecGeo = (TC * g->stride) % 4 == 0 && (g->Win % 4) == 0;
+    p->cplane = pad_to_residue(NI * p->inRows * p->pitch, vecGeo ? 4 : 2);
     // 1x1, stride 1, unpadded, single full-resolution source: the x tile is 64 contiguous pixels per
     // channel, staged like the G tile (swizzled 64-float rows, 16-byte DMA)
     p->xrow = (KHW == 1 && g->stride == 1 && g->pad_top == 0 && g->pad_left == 0 && !g->up1 && g->C2 == 0 &&
                TC >= 4 && (g->Win % 4) == 0 && g->Hin == g->Hout && g->Win == g->Wout)
                   ? 1
                   : 0;
-    if (p->xrow) p->cplane = 64;
+    if (p->xrow) {
+        p->cplane = 64;
+        p->colOff = 0;
+    }
     // channels per chunk: up to 20 k-tiles of 16 rows (IT = 5 per wave)
     int CKW = std::max(1, std::min(Cin, (5 * 4 * 16) / KHW));
     if (KHW == 9) CKW = std::min(CKW, 32);
@@ -937,7 +1043,7 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     if (itw > 5) return false;
     p->ldsBytes = lds(CKW);
     const int per = p->nChunks * p->nblkN;
-    int groups = std::max(1, std::min(p->nTiles, sprk::cdiv(512, per)));
+    int groups = std::max(1, std::min(p->nTiles, sprk::cdiv(dbg_int("SPRK_WG_BLOCKS", 512), per)));  // > CU count: not every CU may be free
     p->tilesPerGroup = sprk::cdiv(p->nTiles, groups);
     p->groups = sprk::cdiv(p->nTiles, p->tilesPerGroup);
     p->wsBytes = ((size_t)kZeroFloats + (size_t)p->groups * Cin * KHW * p->CoutP) * sizeof(float);
@@ -972,7 +1078,7 @@ extern "C" {
 size_t sprk_conv2d_fwd_ws_bytes(const sprk_conv_geom *g) {
     if (!g) return 0;
     FwdPlan p;
-    if (!plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, &p)) return 0;
+    if (!plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, g->pad_left, &p)) return 0;
     return p.wsBytes;
 }
 
@@ -982,7 +1088,7 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
     SPRK_REQUIRE(x && w && y, "conv2d_fwd: null tensor");
     SPRK_REQUIRE(g->C2 == 0 || x2, "conv2d_fwd: C2 > 0 but x2 is null");
     hipStream_t s = (hipStream_t)stream;
-    sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE};
+    sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE, 0};
     if (!ep) ep = &e0;
     SPRK_REQUIRE(!ep->scale || ep->shift, "conv2d_fwd: scale without shift");
     if (sprk::g_naive) {
@@ -992,7 +1098,7 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
         return sprk::check_launch("conv_fwd_direct");
     }
     FwdPlan p;
-    SPRK_REQUIRE(plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, &p),
+    SPRK_REQUIRE(plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, g->pad_left, &p),
                  "conv2d_fwd: geometry does not fit LDS");
     if (ws_bytes < p.wsBytes || !ws) {
         sprk::set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, p.wsBytes);
@@ -1011,6 +1117,7 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
     a.KH = g->KH; a.KW = g->KW; a.stride = g->stride; a.dil = g->dil; a.padT = g->pad_top; a.padL = g->pad_left;
     a.act = ep->act;
     a.resH = ep->res_h; a.resW = ep->res_w; a.resOff = ep->res_off;
+    a.up2 = ep->up2;
     fill_args(a, p);
     a.vec4 = (g->Wout % 4 == 0) && (p.lgTC >= 2) && (((uintptr_t)y & 15) == 0);
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * g->KH * g->KW;
@@ -1023,7 +1130,7 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
 size_t sprk_conv2d_bwd_data_ws_bytes(const sprk_conv_geom *g) {
     if (!g || g->stride != 1) return 0;
     FwdPlan p;
-    if (!plan_fwd(g->N, g->Cout, g->C1 + g->C2, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, &p)) return 0;
+    if (!plan_fwd(g->N, g->Cout, g->C1 + g->C2, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, (g->KW - 1) * g->dil - g->pad_left, &p)) return 0;
     return p.wsBytes;
 }
 
@@ -1034,7 +1141,7 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
     hipStream_t s = (hipStream_t)stream;
     const int Cin = g->C1 + g->C2;
     if (sprk::g_naive || g->stride != 1) {
-        sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE};
+        sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE, 0};
         DirectArgs a{nullptr, nullptr, w, gy, gin, *g, e0};
         const long total = (long)g->N * Cin * g->Hin * g->Win;
         hipLaunchKernelGGL(conv_bwd_data_direct_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, s, a);
@@ -1042,7 +1149,7 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
     }
     // gin = correlation of gy with the flipped, channel-transposed kernel
     FwdPlan p;
-    SPRK_REQUIRE(plan_fwd(g->N, g->Cout, Cin, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, &p),
+    SPRK_REQUIRE(plan_fwd(g->N, g->Cout, Cin, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, (g->KW - 1) * g->dil - g->pad_left, &p),
                  "conv2d_bwd_data: geometry does not fit LDS");
     if (ws_bytes < p.wsBytes || !ws) {
         sprk::set_error("conv2d_bwd_data: workspace %zu < %zu", ws_bytes, p.wsBytes);
@@ -1085,7 +1192,7 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     WgPlan p;
     const bool ok = plan_wgrad(g, &p);
     if (sprk::g_naive || !ok) {
-        sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE};
+        sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE, 0};
         DirectArgs a{x, x2, nullptr, gy, gw, *g, e0};
         hipLaunchKernelGGL(conv_bwd_weight_direct_kernel, dim3(g->Cout * Cin), dim3(256), 0, s, a);
         return sprk::check_launch("conv_bwd_weight_direct");
@@ -1109,9 +1216,15 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     a.lgTC = p.lgTC; a.lgTR = p.lgTR; a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.nTiles = p.nTiles;
     a.tilesPerGroup = p.tilesPerGroup;
     a.CKW = p.CKW; a.ioffN = p.ioffN;
-    a.inRows = p.inRows; a.inCols = p.inCols; a.pitch = p.pitch; a.cplane = p.cplane;
-    a.invImg = 1.0f / (float)(p.inRows * p.inCols);
-    a.invInCols = 1.0f / (float)p.inCols;
+    a.inRows = p.inRows; a.inCols = p.inCols; a.pitch = p.pitch; a.cplane = p.cplane; a.colOff = p.colOff;
+    a.invImg = 1.0f / (float)(p.inRows * p.pitch);
+    a.invPitch = 1.0f / (float)p.pitch;
+    {
+        const bool geo = ((1 << p.lgTC) * g->stride) % 4 == 0 && (g->Win % 4) == 0;
+        a.vec1 = (geo && !g->up1 && aligned16(x)) ? 1 : 0;
+        a.vec2 = (geo && x2 && aligned16(x2)) ? 1 : 0;
+        a.deal = dbg_int("SPRK_DEAL", 1);
+    }
     a.xrow = p.xrow;
     a.g4 = (p.lgTC >= 2 && (g->Wout % 4) == 0 && ((uintptr_t)gy & 15) == 0) ? 1 : 0;
     if (a.xrow && (((uintptr_t)x & 15) != 0)) {
@@ -1148,19 +1261,20 @@ size_t sprk_act_bwd_ws_bytes(int N, int C, int HW) {
     return (size_t)C * act_nsplit(N, C) * sizeof(float);
 }
 
-int sprk_act_bwd(const float *g, const float *y, float *gpre, float *gbias, int act, int N, int C, int HW, void *ws,
-                 size_t ws_bytes, void *stream) {
-    SPRK_REQUIRE(g && N > 0 && C > 0 && HW > 0, "act_bwd: bad arguments");
+int sprk_act_bwd(const float *g, const float *y, float *gpre, float *gbias, int act, int N, int C, int H, int W,
+                 int up2, void *ws, size_t ws_bytes, void *stream) {
+    SPRK_REQUIRE(g && N > 0 && C > 0 && H > 0 && W > 0, "act_bwd: bad arguments");
     SPRK_REQUIRE(act == SPRK_ACT_NONE || (y && gpre), "act_bwd: activation needs the saved output and gpre");
+    SPRK_REQUIRE(!up2 || (gpre && gpre != g), "act_bwd: up2 needs a separate low-resolution gpre");
     hipStream_t s = (hipStream_t)stream;
-    if (act == SPRK_ACT_NONE && !gbias) return SPRK_OK;
+    if (act == SPRK_ACT_NONE && !gbias && !up2) return SPRK_OK;
     const int ns = act_nsplit(N, C);
     if (gbias && (ws_bytes < (size_t)C * ns * sizeof(float) || !ws)) {
         sprk::set_error("act_bwd: workspace too small");
         return SPRK_EWORKSPACE;
     }
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(C, ns), dim3(256), 0, s, g, y, gpre, gbias ? (float *)ws : nullptr, act, N, C, HW,
-                       ns);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(C, ns), dim3(256), 0, s, g, y, gpre, gbias ? (float *)ws : nullptr, act, N, C,
+                       H * W, W, up2, ns);
     if (int rc = sprk::check_launch("act_bwd")) return rc;
     if (gbias) {
         hipLaunchKernelGGL(bias_reduce_kernel, dim3(sprk::cdiv(C, 64)), dim3(64), 0, s, (const float *)ws, gbias, C, ns);

@@ -68,9 +68,11 @@ class Conv2d(nn.Module):
         p = self.padding
         return (p, p, p, p)
 
-    def forward(self, x, skip=None, up=False):
+    def forward(self, x, skip=None, up=False, up_out=False):
+        """skip: second input source (channel concat); up: x is half resolution, upsampled on load;
+        up_out: write the output nearest-upsampled x2 (the nn.Upsample that follows in the reference)."""
         return ops.conv2d(x, self.weight, self.bias, x2=skip, up1=up, stride=self.stride, dil=self.dilation,
-                          pad=self._pad(), act=self.act)
+                          pad=self._pad(), act=self.act, up_out=up_out)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%d, padding=%d, dilation=%d, act=%d%s" % (
@@ -209,10 +211,12 @@ class DualNetwork(_UNetBase):
         pool3 = self._run_pool(e3, e3[0](pool2))
         pool4 = self._run_pool(e4, e4[0](pool3))
         pool5 = self._run_pool(e5, e5[0](pool4))
-        t = e6[0](pool5)
-        for blk, skip in ((self.decode_block_5, pool4), (self.decode_block_4, pool3), (self.decode_block_3, pool2),
-                          (self.decode_block_2, pool1), (self.decode_block_1, x)):
-            t = blk[2](blk[0](t, skip=skip, up=True))
+        # every nn.Upsample of the reference is fused into the stores of the conv that feeds it
+        t = e6[0](pool5, up_out=True)
+        for blk, skip, up_out in ((self.decode_block_5, pool4, True), (self.decode_block_4, pool3, True),
+                                  (self.decode_block_3, pool2, True), (self.decode_block_2, pool1, True),
+                                  (self.decode_block_1, x, False)):
+            t = blk[2](blk[0](t, skip=skip), up_out=up_out)
         if self._blindspot:
             t = ops.unrot4_shift_concat(t)
         t = self.output_block[2](self.output_block[0](t))
@@ -265,9 +269,10 @@ class DualNetworkShallow(_UNetBase):
         pool1 = self._run_pool(e1, e1[2](e1[0](x)))
         pool2 = self._run_pool(e2, e2[0](pool1))
         pool3 = self._run_pool(e3, e3[0](pool2))
-        t = e6[0](pool3)
-        for blk, skip in ((self.decode_block_5, pool2), (self.decode_block_2, pool1), (self.decode_block_1, x)):
-            t = blk[2](blk[0](t, skip=skip, up=True))
+        t = e6[0](pool3, up_out=True)
+        for blk, skip, up_out in ((self.decode_block_5, pool2, True), (self.decode_block_2, pool1, True),
+                                  (self.decode_block_1, x, False)):
+            t = blk[2](blk[0](t, skip=skip), up_out=up_out)
         t = self.output_block[2](self.output_block[0](t))
         return self.output_conv(t)
 

@@ -55,13 +55,16 @@ def make_geom(x, x2, w, up1, stride, dil, pad, out_hw=None):
     return ConvGeom(N, C1, C2, Hin, Win, 1 if up1 else 0, Cout, Hout, Wout, KH, KW, stride, dil, pt, pl)
 
 
-def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None, res=None, res_off=0):
-    """Raw forward launch (no autograd).  Returns y [N,Cout,Hout,Wout]."""
+def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None, res=None, res_off=0, up_out=False):
+    """Raw forward launch (no autograd).  Returns y [N,Cout,Hout,Wout] ([N,Cout,2Hout,2Wout] with
+    ``up_out``: nearest x2 upsampling fused into the store)."""
     L = _lib.lib()
     _need_gpu(x, x2, w, bias, scale, shift, res)
-    y = torch.empty((g.N, g.Cout, g.Hout, g.Wout), dtype=torch.float32, device=x.device)
+    m = 2 if up_out else 1
+    y = torch.empty((g.N, g.Cout, g.Hout * m, g.Wout * m), dtype=torch.float32, device=x.device)
     ep = ConvEpilogue(_p(bias), _p(scale), _p(shift), _p(res),
-                      0 if res is None else res.shape[2], 0 if res is None else res.shape[3], res_off, act)
+                      0 if res is None else res.shape[2], 0 if res is None else res.shape[3], res_off, act,
+                      1 if up_out else 0)
     nb = L.sprk_conv2d_fwd_ws_bytes(ctypes.byref(g))
     ws = _ws(nb, x)
     check(L.sprk_conv2d_fwd(_p(x), _p(x2), _p(w), _p(y), ctypes.byref(g), ctypes.byref(ep), _p(ws), nb, _stream()),
@@ -71,14 +74,15 @@ def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None,
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x2, w, bias, up1, stride, dil, pad, act):
+    def forward(ctx, x, x2, w, bias, up1, stride, dil, pad, act, up_out):
         x = x.contiguous()
         x2 = None if x2 is None else x2.contiguous()
         w = w.contiguous()
         g = make_geom(x, x2, w, up1, stride, dil, pad)
-        y = conv2d_forward(x, x2, w, g, bias=bias, act=act)
+        y = conv2d_forward(x, x2, w, g, bias=bias, act=act, up_out=up_out)
         ctx.geom = g
         ctx.act = act
+        ctx.up_out = up_out
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
         return y
@@ -93,14 +97,18 @@ class _Conv2dFn(torch.autograd.Function):
         gx = gx2 = gw = gb = None
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
         # gradient w.r.t. the pre-activation output (+ bias gradient)
-        if ctx.act != ACT_NONE or need_b:
-            gpre = torch.empty_like(gy) if ctx.act != ACT_NONE else gy
+        up2 = 1 if ctx.up_out else 0
+        if ctx.act != ACT_NONE or need_b or up2:
+            if ctx.act != ACT_NONE or up2:
+                gpre = torch.empty((g.N, g.Cout, g.Hout, g.Wout), dtype=torch.float32, device=gy.device)
+            else:
+                gpre = gy
             if need_b:
                 gb = torch.empty(g.Cout, dtype=torch.float32, device=gy.device)
             nb = L.sprk_act_bwd_ws_bytes(g.N, g.Cout, g.Hout * g.Wout)
             ws = _ws(nb, gy)
-            check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre) if ctx.act != ACT_NONE else None, _p(gb), ctx.act,
-                                 g.N, g.Cout, g.Hout * g.Wout, _p(ws), nb, _stream()), "sprk_act_bwd")
+            check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre) if gpre is not gy else None, _p(gb), ctx.act,
+                                 g.N, g.Cout, g.Hout, g.Wout, up2, _p(ws), nb, _stream()), "sprk_act_bwd")
         else:
             gpre = gy
         if ctx.needs_input_grad[2]:
@@ -131,13 +139,15 @@ class _Conv2dFn(torch.autograd.Function):
                 gx2 = torch.empty_like(x2) if gd.C2 else None
                 check(L.sprk_concat_up_bwd(_p(gin), _p(gx), _p(gx2), gd.N, gd.C1, gd.C2, gd.Hin, gd.Win, gd.up1,
                                            _stream()), "sprk_concat_up_bwd")
-        return gx, gx2, gw, gb, None, None, None, None, None
+        return gx, gx2, gw, gb, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, x2=None, up1=False, stride=1, dil=1, pad=(0, 0, 0, 0), act=ACT_NONE):
-    """y = act(conv(cat(up2(x) if up1 else x, x2), w) + bias); pad = (top, bottom, left, right)."""
+def conv2d(x, w, bias=None, x2=None, up1=False, stride=1, dil=1, pad=(0, 0, 0, 0), act=ACT_NONE, up_out=False):
+    """y = act(conv(cat(up2(x) if up1 else x, x2), w) + bias); pad = (top, bottom, left, right).
+    up_out: return nearest-x2-upsampled y (the upsampling is fused into the conv's stores)."""
     _need_gpu(x, x2, w, bias)
-    return _Conv2dFn.apply(x, x2, w, bias, bool(up1), int(stride), int(dil), tuple(int(p) for p in pad), int(act))
+    return _Conv2dFn.apply(x, x2, w, bias, bool(up1), int(stride), int(dil), tuple(int(p) for p in pad), int(act),
+                           bool(up_out))
 
 
 # ---- U-Net plumbing -----------------------------------------------------------------------------

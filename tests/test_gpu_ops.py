@@ -122,6 +122,30 @@ def test_conv2d_fwd_bwd(case, naive):
         close(dl[3].grad, leaves[3].grad, rel=5e-5, name=name + " gb")
 
 
+def test_conv_fused_upsample_output():
+    """conv + LeakyReLU + nn.Upsample(2, nearest) fused into the stores, and its backward."""
+    from spr_pick_amd import ops
+    g = torch.Generator().manual_seed(9)
+    for shape in ((4, 48, 8, 8), (3, 96, 32, 32), (2, 5, 2, 2)):
+        x = torch.randn(shape, generator=g)
+        w = torch.randn(24, shape[1], 3, 3, generator=g) / 20
+        b = torch.randn(24, generator=g) * 0.1
+        d = dev()
+        xd, wd, bd = (t.to(d).requires_grad_(True) for t in (x, w, b))
+        y = ops.conv2d(xd, wd, bd, pad=(2, 0, 1, 1), act=1, up_out=True)
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+        pre = F.conv2d(F.pad(xr, (1, 1, 2, 0)), wr, br)
+        close(y, F.interpolate(F.leaky_relu(pre, 0.1), scale_factor=2, mode="nearest"), name="up_out y")
+        pos = y.detach().cpu()[:, :, ::2, ::2] > 0
+        yr = F.interpolate(torch.where(pos, pre, pre * 0.1), scale_factor=2, mode="nearest")
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy.double())
+        y.backward(gy.to(d))
+        close(xd.grad, xr.grad, rel=5e-5, name="up_out gx")
+        close(wd.grad, wr.grad, rel=5e-5, name="up_out gw")
+        close(bd.grad, br.grad, rel=5e-5, name="up_out gb")
+
+
 def test_conv_epilogue_residual_affine():
     """Inference epilogue: relu((conv + centre-crop(res)) * scale + shift)."""
     from spr_pick_amd import ops
