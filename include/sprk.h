@@ -118,10 +118,13 @@ int sprk_unrot4_shift_concat_bwd(const float *gf, float *gd, int B, int C, int P
 /* ---- BatchNorm2d (+ optional ReLU), detector: joint_network_v2.py:547,558;
  * feature_extractor.py:287-288,320-324,338-346,412-414.
  * train: batch statistics (biased var for normalisation, unbiased for the running update,
- * momentum 0.1) saved to save_mean/save_invstd [C]; eval: running statistics. */
+ * momentum 0.1) saved to save_mean/save_invstd [C]; eval: running statistics.
+ * ws (sprk_bn_ws_bytes): per-slice fp64 partial sums of the two-kernel reduction. */
+size_t sprk_bn_ws_bytes(int N, int C, int HW);
 int sprk_bn_train_fwd(const float *x, float *y, const float *gamma, const float *beta,
                       float *running_mean, float *running_var, float *save_mean, float *save_invstd,
-                      int N, int C, int HW, float momentum, float eps, int relu, void *stream);
+                      int N, int C, int HW, float momentum, float eps, int relu,
+                      void *ws, size_t ws_bytes, void *stream);
 int sprk_bn_eval_fwd(const float *x, float *y, const float *gamma, const float *beta,
                      const float *running_mean, const float *running_var,
                      int N, int C, int HW, float eps, int relu, void *stream);
@@ -129,7 +132,7 @@ int sprk_bn_eval_fwd(const float *x, float *y, const float *gamma, const float *
 int sprk_bn_train_bwd(const float *gy, const float *x, const float *y, const float *gamma,
                       const float *save_mean, const float *save_invstd,
                       float *gx, float *ggamma, float *gbeta,
-                      int N, int C, int HW, int relu, void *stream);
+                      int N, int C, int HW, int relu, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- per-pixel maths of the pipeline ---------------------------------------------------
  * reparameterize: z = mu + eps * A^2 on out_stats [B,2,H,W] (joint_network_v2.py:469-475) */

@@ -46,9 +46,10 @@ _SIGS = {
     "sprk_rot4_stack_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
     "sprk_unrot4_shift_concat_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
     "sprk_unrot4_shift_concat_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
-    "sprk_bn_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_i, c_vp]),
+    "sprk_bn_ws_bytes": (c_sz, [c_i, c_i, c_i]),
+    "sprk_bn_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_i, c_vp, c_sz, c_vp]),
     "sprk_bn_eval_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_vp]),
-    "sprk_bn_train_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),
+    "sprk_bn_train_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "sprk_reparam_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_vp]),
     "sprk_reparam_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_vp]),
     "sprk_sigmoid_clamp_fwd": (c_i, [c_f, c_f, ctypes.c_long, c_vp]),

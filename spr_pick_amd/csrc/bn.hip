@@ -1,63 +1,134 @@
-// BatchNorm2d (+ optional ReLU) for the detector head.  Training-mode tensors on this path are
-// small ([B,C<=128,<=29,<=29]); one workgroup per channel walks its N*HW elements (L2 resident)
-// three times: mean, centred variance, normalise — the same two-pass statistics torch uses.
+// BatchNorm2d (+ optional ReLU) for the detector head.
+// Training mode: every channel's N*HW elements are split over `S` workgroups (C*S ~ 1024 so the
+// whole chip works even for C = 1); pass A accumulates per-slice sums in fp64 (sum, sum of squares:
+// one pass, no cancellation problem at fp64), pass B combines the S slices in a fixed order,
+// normalises its slice and (slice 0) updates the running statistics.  Backward has the same shape.
 #include "common.h"
 
 namespace {
 
 constexpr int kBlk = 256;
 
-__device__ __forceinline__ float block_sum(float v, float *red) {
+__device__ __forceinline__ double block_sum(double v, double *red) {
     red[threadIdx.x] = v;
     __syncthreads();
     for (int w = kBlk / 2; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
-    const float r = red[0];
+    const double r = red[0];
     __syncthreads();
     return r;
 }
 
-__global__ __launch_bounds__(kBlk) void bn_train_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                            const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta, float *running_mean,
-                                                            float *running_var, float *save_mean, float *save_invstd,
-                                                            int N, int C, int HW, float momentum, float eps, int relu) {
-    __shared__ float red[kBlk];
-    const int c = blockIdx.x;
+// slice s of channel c covers flattened (n, i) elements [s*per, min(M, (s+1)*per))
+__device__ __forceinline__ long elem_index(long e, int c, int C, int HW) {
+    const long n = e / HW, i = e - n * HW;
+    return (n * C + c) * HW + i;
+}
+
+// grid (C, S): partial[(c*S + s)*2 + {0,1}] = sum a, sum b over the slice, where
+// (a, b) = (x, x^2) for the forward and (g, g*(x-mean)*invstd) for the backward
+template <bool BWD>
+__global__ __launch_bounds__(kBlk) void bn_partial_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                          const float *__restrict__ y,
+                                                          const float *__restrict__ save_mean,
+                                                          const float *__restrict__ save_invstd,
+                                                          double *__restrict__ partial, int N, int C, int HW, long per,
+                                                          int relu) {
+    __shared__ double red[kBlk];
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
     const long M = (long)N * HW;
-    float s = 0.f;
-    for (long e = threadIdx.x; e < M; e += kBlk) {
-        const long n = e / HW, i = e - n * HW;
-        s += x[(n * C + c) * HW + i];
+    const long lo = (long)s * per, hi = min(M, lo + per);
+    const float mean = BWD ? save_mean[c] : 0.f, invstd = BWD ? save_invstd[c] : 0.f;
+    double a = 0.0, b = 0.0;
+    for (long e = lo + threadIdx.x; e < hi; e += kBlk) {
+        const long idx = elem_index(e, c, C, HW);
+        if (BWD) {
+            float g = gy[idx];
+            if (relu && !(y[idx] > 0.f)) g = 0.f;
+            a += g;
+            b += (double)g * (double)((x[idx] - mean) * invstd);
+        } else {
+            const float v = x[idx];
+            a += v;
+            b += (double)v * (double)v;
+        }
     }
-    const float mean = block_sum(s, red) / (float)M;
-    s = 0.f;
-    for (long e = threadIdx.x; e < M; e += kBlk) {
-        const long n = e / HW, i = e - n * HW;
-        const float d = x[(n * C + c) * HW + i] - mean;
-        s += d * d;
-    }
-    const float ss = block_sum(s, red);
-    const float var = ss / (float)M;
-    const float invstd = rsqrtf(var + eps);
+    const double ta = block_sum(a, red), tb = block_sum(b, red);
     if (threadIdx.x == 0) {
+        partial[((long)c * S + s) * 2] = ta;
+        partial[((long)c * S + s) * 2 + 1] = tb;
+    }
+}
+
+__global__ __launch_bounds__(kBlk) void bn_train_apply_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, float *running_mean,
+                                                              float *running_var, float *save_mean, float *save_invstd,
+                                                              const double *__restrict__ partial, int N, int C, int HW,
+                                                              long per, float momentum, float eps, int relu) {
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const long M = (long)N * HW;
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < S; ++i) {
+        sa += partial[((long)c * S + i) * 2];
+        sb += partial[((long)c * S + i) * 2 + 1];
+    }
+    const double mean_d = sa / (double)M;
+    double var_d = sb / (double)M - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d, invstd = (float)(1.0 / sqrt(var_d + (double)eps));
+    if (s == 0 && threadIdx.x == 0) {
         save_mean[c] = mean;
         save_invstd[c] = invstd;
         if (running_mean) {
-            const float unbiased = M > 1 ? ss / (float)(M - 1) : var;
+            const double unbiased = M > 1 ? var_d * (double)M / (double)(M - 1) : var_d;
             running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
     }
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    for (long e = threadIdx.x; e < M; e += kBlk) {
-        const long n = e / HW, i = e - n * HW;
-        const long idx = (n * C + c) * HW + i;
+    const long lo = (long)s * per, hi = min(M, lo + per);
+    for (long e = lo + threadIdx.x; e < hi; e += kBlk) {
+        const long idx = elem_index(e, c, C, HW);
         float v = (x[idx] - mean) * invstd * g + b;
         if (relu) v = v > 0.f ? v : 0.f;
         y[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlk) void bn_train_bwd_apply_kernel(const float *__restrict__ gy,
+                                                                  const float *__restrict__ x,
+                                                                  const float *__restrict__ y,
+                                                                  const float *__restrict__ gamma,
+                                                                  const float *__restrict__ save_mean,
+                                                                  const float *__restrict__ save_invstd,
+                                                                  float *__restrict__ gx, float *__restrict__ ggamma,
+                                                                  float *__restrict__ gbeta,
+                                                                  const double *__restrict__ partial, int N, int C,
+                                                                  int HW, long per, int relu) {
+    const int c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const long M = (long)N * HW;
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < S; ++i) {
+        sa += partial[((long)c * S + i) * 2];
+        sb += partial[((long)c * S + i) * 2 + 1];
+    }
+    const float sum_g = (float)sa, sum_gx = (float)sb;
+    if (s == 0 && threadIdx.x == 0) {
+        if (ggamma) ggamma[c] = sum_gx;
+        if (gbeta) gbeta[c] = sum_g;
+    }
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const float k = (gamma ? gamma[c] : 1.f) * invstd, invM = 1.f / (float)M;
+    const long lo = (long)s * per, hi = min(M, lo + per);
+    for (long e = lo + threadIdx.x; e < hi; e += kBlk) {
+        const long idx = elem_index(e, c, C, HW);
+        float g = gy[idx];
+        if (relu && !(y[idx] > 0.f)) g = 0.f;
+        const float xhat = (x[idx] - mean) * invstd;
+        gx[idx] = k * (g - sum_g * invM - xhat * sum_gx * invM);
     }
 }
 
@@ -73,56 +144,38 @@ __global__ void bn_eval_fwd_kernel(const float *__restrict__ x, float *__restric
     }
 }
 
-__global__ __launch_bounds__(kBlk) void bn_train_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x,
-                                                            const float *__restrict__ y,
-                                                            const float *__restrict__ gamma,
-                                                            const float *__restrict__ save_mean,
-                                                            const float *__restrict__ save_invstd,
-                                                            float *__restrict__ gx, float *__restrict__ ggamma,
-                                                            float *__restrict__ gbeta, int N, int C, int HW, int relu) {
-    __shared__ float red[kBlk];
-    const int c = blockIdx.x;
+int slices(int N, int C, int HW) {
     const long M = (long)N * HW;
-    const float mean = save_mean[c], invstd = save_invstd[c];
-    float s1 = 0.f, s2 = 0.f;
-    for (long e = threadIdx.x; e < M; e += kBlk) {
-        const long n = e / HW, i = e - n * HW;
-        const long idx = (n * C + c) * HW + i;
-        float g = gy[idx];
-        if (relu && !(y[idx] > 0.f)) g = 0.f;
-        s1 += g;
-        s2 += g * (x[idx] - mean) * invstd;
-    }
-    const float sum_g = block_sum(s1, red);
-    const float sum_gx = block_sum(s2, red);
-    if (threadIdx.x == 0) {
-        if (ggamma) ggamma[c] = sum_gx;
-        if (gbeta) gbeta[c] = sum_g;
-    }
-    const float gm = gamma ? gamma[c] : 1.f;
-    const float k = gm * invstd, invM = 1.f / (float)M;
-    for (long e = threadIdx.x; e < M; e += kBlk) {
-        const long n = e / HW, i = e - n * HW;
-        const long idx = (n * C + c) * HW + i;
-        float g = gy[idx];
-        if (relu && !(y[idx] > 0.f)) g = 0.f;
-        const float xhat = (x[idx] - mean) * invstd;
-        gx[idx] = k * (g - sum_g * invM - xhat * sum_gx * invM);
-    }
+    long S = 1;
+    while ((long)C * S < 1024 && M / (S * 2) >= 2048) S *= 2;
+    return (int)S;
 }
 
 }  // namespace
 
 extern "C" {
 
+size_t sprk_bn_ws_bytes(int N, int C, int HW) { return (size_t)C * slices(N, C, HW) * 2 * sizeof(double); }
+
 int sprk_bn_train_fwd(const float *x, float *y, const float *gamma, const float *beta, float *running_mean,
                       float *running_var, float *save_mean, float *save_invstd, int N, int C, int HW, float momentum,
-                      float eps, int relu, void *stream) {
+                      float eps, int relu, void *ws, size_t ws_bytes, void *stream) {
     SPRK_REQUIRE(x && y && save_mean && save_invstd && N > 0 && C > 0 && HW > 0, "bn_train_fwd: bad arguments");
     SPRK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running stats mismatch");
-    hipLaunchKernelGGL(bn_train_fwd_kernel, dim3(C), dim3(kBlk), 0, (hipStream_t)stream, x, y, gamma, beta,
-                       running_mean, running_var, save_mean, save_invstd, N, C, HW, momentum, eps, relu);
-    return sprk::check_launch("bn_train_fwd");
+    const int S = slices(N, C, HW);
+    if (!ws || ws_bytes < (size_t)C * S * 2 * sizeof(double)) {
+        sprk::set_error("bn_train_fwd: workspace too small");
+        return SPRK_EWORKSPACE;
+    }
+    const long per = ((long)N * HW + S - 1) / S;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel<false>, dim3(C, S), dim3(kBlk), 0, s, x, (const float *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (double *)ws, N, C, HW,
+                       per, 0);
+    if (int rc = sprk::check_launch("bn_partial")) return rc;
+    hipLaunchKernelGGL(bn_train_apply_kernel, dim3(C, S), dim3(kBlk), 0, s, x, y, gamma, beta, running_mean,
+                       running_var, save_mean, save_invstd, (const double *)ws, N, C, HW, per, momentum, eps, relu);
+    return sprk::check_launch("bn_train_apply");
 }
 
 int sprk_bn_eval_fwd(const float *x, float *y, const float *gamma, const float *beta, const float *running_mean,
@@ -136,12 +189,22 @@ int sprk_bn_eval_fwd(const float *x, float *y, const float *gamma, const float *
 
 int sprk_bn_train_bwd(const float *gy, const float *x, const float *y, const float *gamma, const float *save_mean,
                       const float *save_invstd, float *gx, float *ggamma, float *gbeta, int N, int C, int HW, int relu,
-                      void *stream) {
+                      void *ws, size_t ws_bytes, void *stream) {
     SPRK_REQUIRE(gy && x && save_mean && save_invstd && gx && N > 0 && C > 0 && HW > 0, "bn_train_bwd: bad arguments");
     SPRK_REQUIRE(!relu || y, "bn_train_bwd: relu needs the saved output");
-    hipLaunchKernelGGL(bn_train_bwd_kernel, dim3(C), dim3(kBlk), 0, (hipStream_t)stream, gy, x, y, gamma, save_mean,
-                       save_invstd, gx, ggamma, gbeta, N, C, HW, relu);
-    return sprk::check_launch("bn_train_bwd");
+    const int S = slices(N, C, HW);
+    if (!ws || ws_bytes < (size_t)C * S * 2 * sizeof(double)) {
+        sprk::set_error("bn_train_bwd: workspace too small");
+        return SPRK_EWORKSPACE;
+    }
+    const long per = ((long)N * HW + S - 1) / S;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel<true>, dim3(C, S), dim3(kBlk), 0, s, x, gy, y, save_mean, save_invstd,
+                       (double *)ws, N, C, HW, per, relu);
+    if (int rc = sprk::check_launch("bn_partial_bwd")) return rc;
+    hipLaunchKernelGGL(bn_train_bwd_apply_kernel, dim3(C, S), dim3(kBlk), 0, s, gy, x, y, gamma, save_mean,
+                       save_invstd, gx, ggamma, gbeta, (const double *)ws, N, C, HW, per, relu);
+    return sprk::check_launch("bn_train_bwd_apply");
 }
 
 }  // extern "C"

@@ -593,16 +593,35 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_mfma_kernel(const WgArgs a)
 }
 
 // out[co][c][tap] = sum_g partial[g][(c*KHW+tap)][co]
-__global__ void reduce_partials_kernel(const float *__restrict__ partial, float *__restrict__ out, int K, int Cout,
-                                       int CoutP, int groups) {
+// 64 consecutive slab elements per workgroup x 4 group lanes; every lane sums its quarter of the
+// groups with independent loads in flight, the four partial sums are added in a fixed order.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial,
+                                                              float *__restrict__ out, int K, int Cout, int CoutP,
+                                                              int groups) {
+    __shared__ float red[4][64];
     const long slab = (long)K * CoutP;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < slab; e += (long)gridDim.x * blockDim.x) {
+    const int gl = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long e = (long)blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (e < slab) {
+        const float *p = partial + e;
+        int g = gl;
+#pragma unroll 1
+        for (; g + 28 < groups; g += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(long)(g + 4 * u) * slab];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; g < groups; g += 4) s += p[(long)g * slab];
+    }
+    red[gl][lane] = s;
+    __syncthreads();
+    if (gl == 0 && e < slab) {
         const int co = (int)(e % CoutP);
         const int k = (int)(e / CoutP);
-        if (co >= Cout) continue;
-        float s = 0.f;
-        for (int g = 0; g < groups; ++g) s += partial[(long)g * slab + e];
-        out[(long)co * K + k] = s;
+        if (co < Cout) out[(long)co * K + k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     }
 }
 
@@ -1245,7 +1264,7 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     sprk::prof_end(1, s);
     if (int rc2 = sprk::check_launch("conv_wgrad_mfma")) return rc2;
     const int K = Cin * g->KH * g->KW;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(sprk::ew_blocks((long)K * p.CoutP)), dim3(256), 0, s,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(sprk::cdiv((long)K * p.CoutP, 64)), dim3(256), 0, s,
                        (const float *)(wsf + kZeroFloats), gw, K, g->Cout, p.CoutP, p.groups);
     return sprk::check_launch("reduce_partials");
 }

@@ -240,8 +240,11 @@ class _BNTrainFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-        check(_lib.lib().sprk_bn_train_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                           _p(mean), _p(invstd), N, C, H * W, momentum, eps, int(relu), _stream()),
+        L = _lib.lib()
+        nb = L.sprk_bn_ws_bytes(N, C, H * W)
+        ws = _ws(nb, x)
+        check(L.sprk_bn_train_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                  _p(mean), _p(invstd), N, C, H * W, momentum, eps, int(relu), _p(ws), nb, _stream()),
               "sprk_bn_train_fwd")
         ctx.relu = relu
         ctx.save_for_backward(x, y, gamma, mean, invstd)
@@ -255,8 +258,11 @@ class _BNTrainFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         gg = torch.empty(C, dtype=torch.float32, device=x.device)
         gb = torch.empty(C, dtype=torch.float32, device=x.device)
-        check(_lib.lib().sprk_bn_train_bwd(_p(gy), _p(x), _p(y), _p(gamma), _p(mean), _p(invstd), _p(gx), _p(gg), _p(gb),
-                                           N, C, H * W, int(ctx.relu), _stream()), "sprk_bn_train_bwd")
+        L = _lib.lib()
+        nb = L.sprk_bn_ws_bytes(N, C, H * W)
+        ws = _ws(nb, x)
+        check(L.sprk_bn_train_bwd(_p(gy), _p(x), _p(y), _p(gamma), _p(mean), _p(invstd), _p(gx), _p(gg), _p(gb),
+                                  N, C, H * W, int(ctx.relu), _p(ws), nb, _stream()), "sprk_bn_train_bwd")
         return gx, gg, gb, None, None, None, None, None
 
 
