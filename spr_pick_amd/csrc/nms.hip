@@ -30,15 +30,17 @@ __global__ void nms_init_kernel(const float *__restrict__ sc, unsigned char *__r
     const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
     for (long e = g; e < n; e += (long)gridDim.x * blockDim.x) st[e] = sc[e] > thr ? UNDECIDED : NONCAND;
     for (long e = g; e < ntiles; e += (long)gridDim.x * blockDim.x) tile_und[e] = 1;
-    if (g < 4) counters[g] = 0;
+    if (g < 8) counters[g] = 0;
 }
 
 struct NmsArgs {
     const float *sc;
     unsigned char *st;
     int *tile_und;
+    unsigned long long *keys;   // picks in discovery order: (ordered score bits << 32) | flat index
+    int *counters;              // [0] picks so far, [1] undecided (final), [2] start / [3] end of the last round's picks
+    long cap;
     int H, W, r, tilesX;
-    int first;  // no pick exists yet anywhere: a blocked pixel may stop scanning early
 };
 
 __device__ __forceinline__ int disk_dmax(int r, int adi) {
@@ -48,10 +50,18 @@ __device__ __forceinline__ int disk_dmax(int r, int adi) {
     return d;
 }
 
+__device__ __forceinline__ unsigned ordered_bits(float f);
+
+// One relaxation sweep.  An UNDECIDED pixel scans its potential suppressors (the disk, plus for
+// column 0 the right-border pixels whose footprint wraps onto it) and stops at the first one of
+// higher priority that is UNDECIDED (-> it stays undecided this round) or PICKED (-> it is
+// SUPPRESSED, final).  If there is none it is PICKED (final) and appended to the pick list; the
+// companion kernel then marks the footprints of the round's new picks, so that pixels blocked only
+// by soon-to-be-suppressed neighbours are released in the next sweep.
 template <bool USE_LDS>
 __global__ __launch_bounds__(kBlk) void nms_round_kernel(const NmsArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    __shared__ int s_flag;
+    __shared__ int s_und;
     __shared__ int s_dmax[128];
     const int tile = blockIdx.x;
     if (a.tile_und[tile] == 0) return;  // uniform: every pixel of this tile is decided
@@ -63,6 +73,7 @@ __global__ __launch_bounds__(kBlk) void nms_round_kernel(const NmsArgs a) {
     unsigned char *S = smem_raw + (USE_LDS ? (size_t)side * side * 4 : 0);
 
     for (int i = tid; i <= r && i < 128; i += kBlk) s_dmax[i] = disk_dmax(r, i);
+    if (tid == 0) s_und = 0;
     if (USE_LDS) {
         for (int e = tid; e < side * side; e += kBlk) {
             const int ly = e / side, lx = e - ly * side;
@@ -81,103 +92,108 @@ __global__ __launch_bounds__(kBlk) void nms_round_kernel(const NmsArgs a) {
 
     // each thread owns 4 pixels of the 32x32 tile: rows (tid>>5) + 8k, column tid&31
     const int px = tid & 31;
-    for (int iter = 0; iter < 64; ++iter) {
-        if (tid == 0) s_flag = 0;
-        __syncthreads();
-        unsigned char nst[4];
-        bool changed = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int py = (tid >> 5) + 8 * k;
-            const int y = ty0 + py, x = tx0 + px;
-            nst[k] = NONCAND;
-            if (y >= H || x >= W) continue;
-            const unsigned char cur = USE_LDS ? S[(py + r) * side + px + r] : a.st[(long)y * W + x];
-            nst[k] = cur;
-            if (cur != UNDECIDED) continue;
-            const float my = USE_LDS ? F[(py + r) * side + px + r] : a.sc[(long)y * W + x];
-            bool picked = false, blocked = false;
-            for (int di = -r; di <= r && !picked; ++di) {
-                const int yy = y + di;
-                if (yy < 0 || yy >= H) continue;
-                const int dm = s_dmax[di < 0 ? -di : di];
-                for (int dj = -dm; dj <= dm; ++dj) {
-                    const int xx = x + dj;
-                    if (xx < 0 || xx >= W || (di == 0 && dj == 0)) continue;
-                    const unsigned char s = USE_LDS ? S[(py + r + di) * side + px + r + dj] : a.st[(long)yy * W + xx];
-                    if (s != UNDECIDED && s != PICKED) continue;
-                    const float f = USE_LDS ? F[(py + r + di) * side + px + r + dj] : a.sc[(long)yy * W + xx];
-                    const bool higher = f > my || (f == my && (di > 0 || (di == 0 && dj > 0)));
-                    if (!higher) continue;
-                    if (s == PICKED) {
-                        picked = true;
-                        break;
-                    }
-                    blocked = true;
-                    if (a.first) break;
-                }
-                if (a.first && blocked) break;
-            }
-            // x-overflow wrap of picks near the right border onto column 0 of the next row
-            if (!picked && x == 0 && y >= 1) {
-                const long me = (long)y * W;
-                for (int yy = max(0, y - 1 - r); yy <= min(H - 1, y - 1 + r) && !picked; ++yy) {
-                    const int adi = yy > y - 1 ? yy - (y - 1) : (y - 1) - yy;
-                    const int dm = s_dmax[adi];
-                    for (int xx = max(0, W - dm); xx < W; ++xx) {  // xx + dm >= W
-                        const long j = (long)yy * W + xx;
-                        if (j == me) continue;
-                        const unsigned char s = a.st[j];
-                        if (s != UNDECIDED && s != PICKED) continue;
-                        const float f = a.sc[j];
-                        const bool higher = f > my || (f == my && j > me);
-                        if (!higher) continue;
-                        if (s == PICKED) {
-                            picked = true;
-                            break;
-                        }
-                        blocked = true;
-                    }
-                }
-            }
-            if (picked) {
-                nst[k] = SUPPRESSED;
-                changed = true;
-            } else if (!blocked) {
-                nst[k] = PICKED;
-                changed = true;
-            }
-        }
-        __syncthreads();  // all scans of this sweep are done before any state changes
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int py = (tid >> 5) + 8 * k;
-            const int y = ty0 + py, x = tx0 + px;
-            if (y >= H || x >= W) continue;
-            if (USE_LDS) S[(py + r) * side + px + r] = nst[k];
-            if (nst[k] == PICKED || nst[k] == SUPPRESSED) a.st[(long)y * W + x] = nst[k];
-        }
-        if (changed) s_flag = 1;
-        __syncthreads();
-        const int again = s_flag;
-        __syncthreads();
-        if (!again || !USE_LDS || a.first) break;
-    }
-    // remaining undecided pixels of this tile
     int und = 0;
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         const int py = (tid >> 5) + 8 * k;
         const int y = ty0 + py, x = tx0 + px;
         if (y >= H || x >= W) continue;
         const unsigned char cur = USE_LDS ? S[(py + r) * side + px + r] : a.st[(long)y * W + x];
-        und += cur == UNDECIDED;
+        if (cur != UNDECIDED) continue;
+        const float my = USE_LDS ? F[(py + r) * side + px + r] : a.sc[(long)y * W + x];
+        int verdict = 0;  // 0 none found, 1 blocked by an undecided, 2 covered by a pick
+        for (int di = -r; di <= r && !verdict; ++di) {
+            const int yy = y + di;
+            if (yy < 0 || yy >= H) continue;
+            const int dm = s_dmax[di < 0 ? -di : di];
+            for (int dj = -dm; dj <= dm; ++dj) {
+                const int xx = x + dj;
+                if (xx < 0 || xx >= W || (di == 0 && dj == 0)) continue;
+                const unsigned char s = USE_LDS ? S[(py + r + di) * side + px + r + dj] : a.st[(long)yy * W + xx];
+                if (s != UNDECIDED && s != PICKED) continue;
+                const float f = USE_LDS ? F[(py + r + di) * side + px + r + dj] : a.sc[(long)yy * W + xx];
+                if (f > my || (f == my && (di > 0 || (di == 0 && dj > 0)))) {
+                    verdict = s == PICKED ? 2 : 1;
+                    break;
+                }
+            }
+        }
+        // x-overflow wrap of picks near the right border onto column 0 of the next row
+        if (!verdict && x == 0 && y >= 1) {
+            const long me = (long)y * W;
+            for (int yy = max(0, y - 1 - r); yy <= min(H - 1, y - 1 + r) && !verdict; ++yy) {
+                const int adi = yy > y - 1 ? yy - (y - 1) : (y - 1) - yy;
+                const int dm = s_dmax[adi];
+                for (int xx = max(0, W - dm); xx < W; ++xx) {  // xx + dm >= W
+                    const long j = (long)yy * W + xx;
+                    if (j == me) continue;
+                    const unsigned char s = a.st[j];
+                    if (s != UNDECIDED && s != PICKED) continue;
+                    const float f = a.sc[j];
+                    if (f > my || (f == my && j > me)) {
+                        verdict = s == PICKED ? 2 : 1;
+                        break;
+                    }
+                }
+            }
+        }
+        if (verdict == 2) {
+            a.st[(long)y * W + x] = SUPPRESSED;
+        } else if (verdict == 0) {
+            a.st[(long)y * W + x] = PICKED;
+            const int pos = atomicAdd(&a.counters[0], 1);
+            if (pos < a.cap) a.keys[pos] = ((unsigned long long)ordered_bits(my) << 32) | (unsigned)((long)y * W + x);
+        } else {
+            ++und;
+        }
     }
-    if (tid == 0) s_flag = 0;
+    if (und) atomicAdd(&s_und, und);
     __syncthreads();
-    if (und) atomicAdd(&s_flag, und);
+    if (tid == 0) a.tile_und[tile] = s_und;
+}
+
+// counters[2..3] = [start, end) of the picks appended by the sweep that just ran
+__global__ void nms_snapshot_kernel(int *counters) {
+    counters[2] = counters[3];
+    counters[3] = counters[0];
+}
+
+// footprint of every new pick: UNDECIDED pixels of LOWER priority become SUPPRESSED (a pick only
+// suppresses what the greedy walk visits after it); the footprint is the clipped disk plus, when the
+// disk overflows the right border, column 0 of the following row (the reference's clip-to-W quirk)
+__global__ __launch_bounds__(kBlk) void nms_suppress_kernel(const NmsArgs a) {
+    __shared__ int s_dmax[128];
+    const int r = a.r, H = a.H, W = a.W;
+    for (int i = threadIdx.x; i <= r && i < 128; i += kBlk) s_dmax[i] = disk_dmax(r, i);
     __syncthreads();
-    if (tid == 0) a.tile_und[tile] = s_flag;
+    const long start = a.counters[2], end = min((long)a.counters[3], a.cap);
+    const int span = 2 * r + 1;
+    for (long p = start + blockIdx.x; p < end; p += gridDim.x) {
+        const unsigned long long key = a.keys[p];
+        const unsigned idx = (unsigned)(key & 0xFFFFFFFFull);
+        const int yy = (int)(idx / (unsigned)W), xx = (int)(idx % (unsigned)W);
+        for (int e = threadIdx.x; e < span * (span + 1); e += kBlk) {
+            const int di = e / (span + 1) - r, c = e % (span + 1);
+            const int dm = s_dmax[di < 0 ? -di : di];
+            int ty, tx;
+            if (c < span) {  // disk element
+                const int dj = c - r;
+                if (dj < -dm || dj > dm) continue;
+                ty = yy + di;
+                tx = xx + dj;
+                if (ty < 0 || ty >= H || tx < 0 || tx >= W) continue;
+            } else {         // wrap element of this row
+                if (xx + dm < W) continue;
+                ty = min(max(yy + di, 0), H) + 1;
+                tx = 0;
+                if (ty >= H) continue;
+            }
+            const long t = (long)ty * W + tx;
+            if (t == (long)idx || a.st[t] != UNDECIDED) continue;
+            const unsigned long long tk = ((unsigned long long)ordered_bits(a.sc[t]) << 32) | (unsigned)t;
+            if (tk < key) a.st[t] = SUPPRESSED;
+        }
+    }
 }
 
 __device__ __forceinline__ unsigned ordered_bits(float f) {
@@ -189,19 +205,19 @@ __device__ __forceinline__ float from_ordered(unsigned o) {
     return __uint_as_float(b);
 }
 
-__global__ void nms_collect_kernel(const float *__restrict__ sc, const unsigned char *__restrict__ st, long n,
-                                   unsigned long long *__restrict__ keys, long cap, int *__restrict__ counters,
-                                   const int *__restrict__ tile_und, int ntiles) {
-    const long g = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (long e = g; e < n; e += (long)gridDim.x * blockDim.x) {
-        if (st[e] == PICKED) {
-            const int pos = atomicAdd(&counters[0], 1);
-            if (pos < cap) keys[pos] = ((unsigned long long)ordered_bits(sc[e]) << 32) | (unsigned)e;
-        }
-    }
+__global__ void nms_count_kernel(int *__restrict__ counters, const unsigned char *__restrict__ st, long n) {
     int und = 0;
-    for (long e = g; e < ntiles; e += (long)gridDim.x * blockDim.x) und += tile_und[e];
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x)
+        und += st[e] == UNDECIDED;
     if (und) atomicAdd(&counters[1], und);
+}
+
+// copy the discovery-order pick list into the sort buffer, zero padded to `cap`
+__global__ void nms_fill_sort_kernel(const unsigned long long *__restrict__ picks, unsigned long long *__restrict__ keys,
+                                     const int *__restrict__ counters, long cap) {
+    const long n = min((long)counters[0], cap);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < cap; e += (long)gridDim.x * blockDim.x)
+        keys[e] = e < n ? picks[e] : 0ull;
 }
 
 // ---- bitonic sort, descending, on `cap` (power of two >= kSortL) 64-bit keys -------------------
@@ -267,7 +283,7 @@ __global__ void nms_emit_kernel(const unsigned long long *__restrict__ keys, con
 }
 
 struct NmsWs {
-    size_t off_state, off_tiles, off_counters, off_keys, total;
+    size_t off_state, off_tiles, off_counters, off_keys, off_picks, total;
     long cap;
     int ntiles, tilesX;
 };
@@ -287,6 +303,8 @@ NmsWs nms_layout(int H, int W, int max_out) {
     w.off_counters = o;
     o += 256;
     w.off_keys = o;
+    o += (size_t)cap * 8;
+    w.off_picks = o;
     o += (size_t)cap * 8;
     w.total = o;
     return w;
@@ -317,36 +335,35 @@ int sprk_nms2d(const float *scores, int H, int W, int r, float threshold, float 
     int *tile_und = (int *)(base + L.off_tiles);
     int *counters = (int *)(base + L.off_counters);
     unsigned long long *keys = (unsigned long long *)(base + L.off_keys);
+    unsigned long long *picks = (unsigned long long *)(base + L.off_picks);
     const long n = (long)H * W;
     if (!resume) {
         hipLaunchKernelGGL(nms_init_kernel, dim3(sprk::ew_blocks(n)), dim3(256), 0, s, scores, st, n, threshold,
                            tile_und, L.ntiles, counters);
         if (int rc = sprk::check_launch("nms_init")) return rc;
     } else {
-        if (hipMemsetAsync(counters, 0, 16, s) != hipSuccess) {
+        if (hipMemsetAsync(counters + 1, 0, 4, s) != hipSuccess) {
             sprk::set_error("nms2d: memset failed");
             return SPRK_ELAUNCH;
         }
     }
-    NmsArgs a{scores, st, tile_und, H, W, r, L.tilesX, 0};
+    NmsArgs a{scores, st, tile_und, picks, counters, L.cap, H, W, r, L.tilesX};
     const bool lds = r <= kMaxLdsR;
     const int side = TS + 2 * r;
     const size_t shm = lds ? (size_t)side * side * 5 : 0;
     for (int it = 0; it < rounds; ++it) {
-        a.first = (!resume && it == 0) ? 1 : 0;
         if (lds)
             hipLaunchKernelGGL(nms_round_kernel<true>, dim3(L.ntiles), dim3(kBlk), shm, s, a);
         else
             hipLaunchKernelGGL(nms_round_kernel<false>, dim3(L.ntiles), dim3(kBlk), 0, s, a);
         if (int rc = sprk::check_launch("nms_round")) return rc;
+        hipLaunchKernelGGL(nms_snapshot_kernel, dim3(1), dim3(1), 0, s, counters);
+        hipLaunchKernelGGL(nms_suppress_kernel, dim3(512), dim3(kBlk), 0, s, a);
+        if (int rc = sprk::check_launch("nms_suppress")) return rc;
     }
-    if (hipMemsetAsync(keys, 0, (size_t)L.cap * 8, s) != hipSuccess) {
-        sprk::set_error("nms2d: memset failed");
-        return SPRK_ELAUNCH;
-    }
-    hipLaunchKernelGGL(nms_collect_kernel, dim3(sprk::ew_blocks(n)), dim3(256), 0, s, scores, st, n, keys, L.cap,
-                       counters, tile_und, L.ntiles);
-    if (int rc = sprk::check_launch("nms_collect")) return rc;
+    hipLaunchKernelGGL(nms_count_kernel, dim3(sprk::ew_blocks(n)), dim3(256), 0, s, counters, st, n);
+    hipLaunchKernelGGL(nms_fill_sort_kernel, dim3(sprk::ew_blocks(L.cap)), dim3(256), 0, s, picks, keys, counters, L.cap);
+    if (int rc = sprk::check_launch("nms_fill_sort")) return rc;
     const int nchunks = (int)(L.cap / kSortL);
     hipLaunchKernelGGL(bitonic_local_kernel, dim3(nchunks), dim3(kBlk), 0, s, keys, 0L, 0);
     if (int rc = sprk::check_launch("bitonic_local")) return rc;
