@@ -179,6 +179,15 @@ def main():
     value = patches / dt
     nm, n0, ms0, fl0 = prof[0]
     achieved = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read in-process; they are
+    # collected with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) on
+    # this same command and committed under profiles/ 
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            traffic = json.load(f)["kernels"]["conv_mfma_kernel"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {
         "metric": "train_patches_per_sec", "value": value, "unit": "patches/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -189,7 +198,7 @@ def main():
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "patch": 64,
                    "parallelism": "dp%d (flat fp32 grad all-reduce, %d floats)" % (world, sync.numel()) if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "kernel": nm, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                      "launches": n0, "avg_launch_ms": ms0 / max(n0, 1)},
         "whole_step_mfma_frac": value / world * FLOP_PER_PATCH_STEP / (PEAK_FP32_MFMA_TFLOPS * 1e12),
         "wgrad_kernel": {"kernel": prof[1][0], "launches": prof[1][1], "avg_launch_ms": prof[1][2] / max(prof[1][1], 1),

@@ -193,7 +193,7 @@ struct ConvArgs {
     int inRows, inCols, pitch, cplane, colOff;
     int ldw;
     int resH, resW, resOff;
-    int vec4, vec1, vec2, up2, deal;
+    int vec4, vec1, vec2, up2, deal, xcdRemap;
     float invImg, invPitch;
 };
 
@@ -275,7 +275,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
     constexpr int TM = 64 * MT;
     const int lgT = a.lgTC + a.lgTR;
     const int NI = TM >> lgT;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+    // give every XCD a contiguous run of tiles — vertically adjacent tiles share their halo rows in L2.
+    // (bijective remap; only a speed matter, see cdna_hip_programming.md T1)
     int bid = blockIdx.x;
+    if (a.xcdRemap) {
+        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
     const int tx = bid % a.tilesX;
     bid /= a.tilesX;
     const int ty = bid % a.tilesY;
@@ -830,6 +837,11 @@ __global__ void concat_up_bwd_kernel(const float *__restrict__ gin, float *__res
 // ------------------------------------------------------------------------------------------
 constexpr size_t kLdsLimit = 160 * 1024;
 
+int dbg_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 struct FwdPlan {
     int MT, NT, lgTC, lgTR, tilesX, tilesY, imgGroups, nblkN;
     int CK, R4, rows;
@@ -908,7 +920,7 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
     p->CK = CK;
     p->R4 = sprk::roundup(CK * KHW, 4);
     p->rows = sprk::cdiv(Ck, CK) * p->R4;
-    p->ldsBytes = lds(CK);
+    p->ldsBytes = std::max(lds(CK), (size_t)dbg_int("SPRK_LDS_MIN", 0));
     p->wsBytes = ((size_t)kZeroFloats + (size_t)p->nblkN * p->rows * p->ldw) * sizeof(float);
     return true;
 }
@@ -952,11 +964,6 @@ int launch_fwd(const ConvArgs &a, const FwdPlan &p, hipStream_t s) {
     }
 }
 
-int dbg_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 bool aligned16(const void *p) {
     static const bool novec = getenv("SPRK_NOVEC") != nullptr;  // debug: force the 4-byte DMA path
     return !novec && (((uintptr_t)p) & 15) == 0;
@@ -983,6 +990,7 @@ void fill_args(ConvArgs &a, const FwdPlan &p) {
     a.vec1 = (geo && !a.up1 && aligned16(a.x)) ? 1 : 0;
     a.vec2 = (geo && a.x2 && aligned16(a.x2)) ? 1 : 0;
     a.deal = dbg_int("SPRK_DEAL", 1);
+    a.xcdRemap = dbg_int("SPRK_XCD", 1);
 }
 
 int transform_weights(const float *w, float *ws, int Cout, int Cin, int KHW, int mode, const FwdPlan &p,
