@@ -105,6 +105,7 @@ struct PlaneGeom {
     int NI, inRows, pitch, colOff, cplane;
     float invImg, invPitch;
     int deal;  // 1: deal (group, channel) items round-robin to waves; 0: whole groups per wave
+    int nw;    // number of waves sharing the DMA issue
 };
 
 // nch channel planes from one source tensor: `base` points at channel 0 of image 0 of the staged
@@ -119,7 +120,8 @@ __device__ __forceinline__ void stage_planes(float *dst, const float *base, long
     const int nGroups = (planeElems + per - 1) / per;
     // work items (group, channel) are dealt round-robin to the issuing waves: every wave walks all
     // groups but only every kIssuers-th channel, so the issue load is even whatever nGroups is
-    const int gstart = g.deal ? 0 : lw, gstep = g.deal ? 1 : kIssuers, cstep = g.deal ? kIssuers : 1;
+    const int nw = g.nw;
+    const int gstart = g.deal ? 0 : lw, gstep = g.deal ? 1 : nw, cstep = g.deal ? nw : 1;
     for (int gi = gstart; gi < nGroups; gi += gstep) {
         const int e = vec ? gi * 256 + lane * 4 : gi * 64 + lane;
         const int il = fast_div(e, g.invImg);
@@ -129,7 +131,7 @@ __device__ __forceinline__ void stage_planes(float *dst, const float *base, long
         const int n = n0 + il, iy = iy0 + r, ix = ixa + j;
         const bool inb = e < planeElems;
         const bool ok = inb && n < N && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-        const int cl0 = g.deal ? (lw + kIssuers - (gi % kIssuers)) % kIssuers : 0;
+        const int cl0 = g.deal ? (lw + nw - (gi % nw)) % nw : 0;
         const float *p = base + (long)n * imgStride + (up ? (long)(iy >> 1) * Ws + (ix >> 1) : (long)iy * Ws + ix) +
                          (long)cl0 * cs;
         long step = (long)cstep * cs;
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1, a.vec1, a.vec2};
-    const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal};
+    const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal, 4};
     const float *wslab = a.wT + (long)nb * a.rows * a.ldw;
     int tab_cke0 = -1, tab_cke1 = -1;
 
@@ -418,35 +420,50 @@ struct WgArgs {
     int CKW;                 // input channels per blockIdx.y
     int ioffN;               // ints reserved for the k-row offset table
     int inRows, inCols, pitch, cplane, colOff;
-    int xrow, g4, vec1, vec2, deal;
+    int xrow, g4, vec1, vec2, deal, dbg;
     float invImg, invPitch;
 };
 
-// one 64-pixel tile: 16 k-steps of MFMAs on NIT k-tiles x NT cout-tiles (branch free, fully unrolled
-// so that the LDS reads of step ks+1 are scheduled under the MFMAs of step ks)
-template <int NIT, int IT, int NT>
+// one 64-pixel tile: 16 k-steps of MFMAs on NIT k-tiles x NT cout-tiles.  Branch free and software
+// pipelined by hand: the LDS operands of step ks+1 are fetched into a second register set before the
+// MFMAs of step ks are issued (with one wave per SIMD nothing else hides the LDS latency).
+template <int NIT, int IT, int NT, bool XROW>
 __device__ __forceinline__ void wgrad_tile(f32x4 (&acc)[IT][NT], const float *x_lds, const float *g_lds,
-                                           const int *pixoff, const int (&ioffv)[IT], int l15, int lq, int gsw,
-                                           int xrow) {
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
+                                           const int *pixoff, const int (&ioffv)[IT], int l15, int lq, int gsw) {
+    // (g_lds already points at this wave's first cout row)
+    float a0[NIT], b0[NT], a1[NIT], b1[NT];
+    auto load = [&](int ks, float (&av)[NIT], float (&bv)[NT]) {
         const int gp = ((ks ^ gsw) << 2) | lq;
-        const int xo = xrow ? gp : pixoff[ks * 4 + lq];
-        float av[NIT], bv[NT];
+        const int xo = XROW ? gp : pixoff[ks * 4 + lq];
 #pragma unroll
         for (int t = 0; t < NIT; ++t) av[t] = x_lds[ioffv[t] + xo];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bv[nt] = g_lds[(nt * 16 + l15) * 64 + gp];
+    };
+    auto mma = [&](const float (&av)[NIT], const float (&bv)[NT]) {
 #pragma unroll
         for (int t = 0; t < NIT; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[nt], acc[t][nt], 0, 0, 0);
+    };
+    load(0, a0, b0);
+#pragma unroll
+    for (int ks = 0; ks < 16; ks += 2) {
+        load(ks + 1, a1, b1);
+        mma(a0, b0);
+        if (ks + 2 < 16) load(ks + 2, a0, b0);
+        mma(a1, b1);
     }
 }
 
-template <int IT, int NT>
-__global__ __launch_bounds__(kBlock) void conv_wgrad_mfma_kernel(const WgArgs a) {
+// WJ = 2: eight waves (two per SIMD); wave (wi, wj) owns k-tiles wi, wi+4, ... x the wj-th half of the
+// NT cout tiles, so that one wave's LDS latency and barrier skew are covered by its SIMD partner.
+template <int IT, int NT, int WJ>
+__global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs a) {
+    constexpr int NTW = NT / WJ;          // cout tiles per wave
+    constexpr int kWgThreads = 256 * WJ;
+    constexpr int kWgWaves = 4 * WJ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int *ioff = reinterpret_cast<int *>(smem);          // [ioffN]
     int *pixoff = ioff + a.ioffN;                       // [64]
@@ -467,11 +484,10 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_mfma_kernel(const WgArgs a)
     const int co0 = blockIdx.z * (NT * 16);
     const long planeO = (long)a.Hout * a.Wout;
     const long planeI = (long)a.Hin * a.Win;
-    const bool loader = kLoaders ? wave >= 4 : true;   // wave-uniform roles
-    const bool compute = kLoaders ? wave < 4 : true;
-    const int lw = kLoaders ? wave - 4 : wave;
+    const int wi = wave & 3, wj = wave >> 2;
+    const int lw = wave;
 
-    for (int k = tid; k < nIT * 16; k += kBlock) {
+    for (int k = tid; k < nIT * 16; k += kWgThreads) {
         int v = 0;
         if (k < kvalid) {
             const int tap = k / cke, cl = k - tap * cke;
@@ -486,12 +502,12 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_mfma_kernel(const WgArgs a)
     }
 
     const TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1, a.vec1, a.vec2};
-    const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal};
+    const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal, kWgWaves};
     // rows of 64 pixels, 16-byte chunks XOR-swizzled by (row & 7): LDS chunk (row, qs) <- pixels
     // 4q..4q+3, q = qs ^ (row & 7).  base: tensor [N][C][H*W]; row r is channel ch0 + r.
     auto stage_rows16 = [&](float *dst, const float *base, int C, long plane, int W, int H, int ch0, int nrows,
                             int chlim, int n0, int oy0, int ox0) {
-        for (int gi = lw; gi * 4 < nrows; gi += kIssuers) {
+        for (int gi = lw; gi * 4 < nrows; gi += kWgWaves) {
             const int idx = gi * 64 + lane;
             const int row = idx >> 4, qs = idx & 15;
             const int p = (qs ^ (row & 7)) << 2;
@@ -511,14 +527,16 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_mfma_kernel(const WgArgs a)
         const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
         float *x_lds = stage_base + b * stageFloats;
         float *g_lds = x_lds + a.CKW * a.cplane;
-        if (a.xrow)
+        if (a.dbg & 1) {
+        } else if (a.xrow)
             stage_rows16(x_lds, a.x, a.C1, planeI, a.Win, a.Hin, c0, cke, Cin, n0, oy0, ox0);
         else
             stage_input_dma(x_lds, src, pg, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, c0, cke, lw, lane);
-        if (a.g4) {
+        if (a.dbg & 2) {
+        } else if (a.g4) {
             stage_rows16(g_lds, a.gy, a.Cout, planeO, a.Wout, a.Hout, co0, NT * 16, a.Cout, n0, oy0, ox0);
         } else {
-            for (int col = lw; col < NT * 16; col += kIssuers) {
+            for (int col = lw; col < NT * 16; col += kWgWaves) {
                 const int p = (((lane >> 2) ^ (col & 7)) << 2) | (lane & 3);
                 const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
                 const int n = n0 + il, oy = oy0 + r, ox = ox0 + c, co = co0 + col;
@@ -532,60 +550,65 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_mfma_kernel(const WgArgs a)
 
     const int t_begin = blockIdx.x * a.tilesPerGroup;
     const int t_end = min(a.nTiles, t_begin + a.tilesPerGroup);
-    if (loader && t_begin < t_end) issue(t_begin, 0);
+    if (t_begin < t_end) issue(t_begin, 0);
     __syncthreads();  // tables visible
     int ioffv[IT];
 #pragma unroll
     for (int t = 0; t < IT; ++t) {
-        const int it = (wave & 3) + 4 * t;
+        const int it = wi + 4 * t;
         ioffv[t] = it < nIT ? ioff[it * 16 + l15] : 0;
     }
-    f32x4 acc[IT][NT];
+    f32x4 acc[IT][NTW];
 #pragma unroll
     for (int t = 0; t < IT; ++t)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int gsw = l15 & 7;
-    const int myIT = (compute && nIT > wave) ? (nIT - wave + 3) >> 2 : 0;  // k-tiles owned by this wave (uniform)
+    const int myIT = nIT > wi ? (nIT - wi + 3) >> 2 : 0;  // k-tiles owned by this wave (uniform)
 
     int bsel = 0;
     for (int tile = t_begin; tile < t_end; ++tile, bsel ^= 1) {
         __syncthreads();  // this tile landed everywhere; previous tile fully consumed
-        if (loader && tile + 1 < t_end) issue(tile + 1, bsel ^ 1);
-        if (!compute) continue;
+        if (tile + 1 < t_end) issue(tile + 1, bsel ^ 1);
         const float *x_lds = stage_base + bsel * stageFloats;
-        const float *g_lds = x_lds + a.CKW * a.cplane;
-        if (myIT >= IT)
-            wgrad_tile<IT, IT, NT>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw, a.xrow);
-        else if (IT > 1 && myIT == IT - 1)
-            wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NT>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw, a.xrow);
-        else if (myIT > 0) {
+        const float *g_lds = x_lds + a.CKW * a.cplane + wj * (NTW * 16 * 64);   // this wave's cout rows
+        if (a.dbg & 4) {
+        } else if (myIT >= IT) {
+            if (a.xrow)
+                wgrad_tile<IT, IT, NTW, true>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
+            else
+                wgrad_tile<IT, IT, NTW, false>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
+        } else if (IT > 1 && myIT == IT - 1) {
+            if (a.xrow)
+                wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NTW, true>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
+            else
+                wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NTW, false>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
+        } else if (myIT > 0) {
             // short tail chunk: predicate per k-tile (rare: last channel chunk of a layer)
 #pragma unroll 2
             for (int ks = 0; ks < 16; ++ks) {
                 const int gp = ((ks ^ gsw) << 2) | lq;
                 const int xo = a.xrow ? gp : pixoff[ks * 4 + lq];
-                float bv[NT];
+                float bv[NTW];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = g_lds[(nt * 16 + l15) * 64 + gp];
+                for (int nt = 0; nt < NTW; ++nt) bv[nt] = g_lds[(nt * 16 + l15) * 64 + gp];
 #pragma unroll
                 for (int t = 0; t < IT; ++t) {
                     if (t < myIT) {
                         const float av = x_lds[ioffv[t] + xo];
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
+                        for (int nt = 0; nt < NTW; ++nt)
                             acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[t][nt], 0, 0, 0);
                     }
                 }
             }
         }
     }
-    if (!compute) return;
     // partial slab of this group: rows = global k (c*KHW + tap), cols = cout (64-byte runs per store)
     float *dst = a.partial + (long)blockIdx.x * Cin * KHW * a.CoutP;
 #pragma unroll
     for (int t = 0; t < IT; ++t) {
-        const int it = wave + 4 * t;
+        const int it = wi + 4 * t;
         if (it >= nIT) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -593,8 +616,8 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_mfma_kernel(const WgArgs a)
             if (k >= kvalid) continue;
             const int tap = k / cke, cl = k - tap * cke;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int co = co0 + nt * 16 + l15;
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int co = co0 + (wj * NTW + nt) * 16 + l15;
                 if (co < a.CoutP) dst[((long)(c0 + cl) * KHW + tap) * a.CoutP + co] = acc[t][nt][j];
             }
         }
@@ -1081,8 +1104,9 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
 
 template <int IT, int NT>
 int launch_wg_one(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
-    if (int rc = set_lds(conv_wgrad_mfma_kernel<IT, NT>, p.ldsBytes)) return rc;
-    hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, NT>), grid, dim3(kBlock), p.ldsBytes, s, a);
+    constexpr int WJ = (NT % 2 == 0) ? 2 : 1;   // two waves per SIMD whenever the cout tiles split evenly
+    if (int rc = set_lds(conv_wgrad_mfma_kernel<IT, NT, WJ>, p.ldsBytes)) return rc;
+    hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, NT, WJ>), grid, dim3(256 * WJ), p.ldsBytes, s, a);
     return SPRK_OK;
 }
 
@@ -1253,6 +1277,7 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
         a.vec1 = (geo && !g->up1 && aligned16(x)) ? 1 : 0;
         a.vec2 = (geo && x2 && aligned16(x2)) ? 1 : 0;
         a.deal = dbg_int("SPRK_DEAL", 1);
+        a.dbg = dbg_int("SPRK_WG_DBG", 0);
     }
     a.xrow = p.xrow;
     a.g4 = (p.lgTC >= 2 && (g->Wout % 4) == 0 && ((uintptr_t)gy & 15) == 0) ? 1 : 0;
