@@ -938,7 +938,7 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
     int CK = std::max(1, std::min(Ck, KHW == 1 ? 16 : std::max(1, 36 / KHW)));
     while (CK > 1 && lds(CK) > 52 * 1024) CK >>= 1;
     // small tiles: longer K-chunks (fewer barriers) while the stages stay small
-    while (CK * 2 <= Ck && CK * 2 * KHW <= 288 && lds(CK * 2) <= 24 * 1024) CK *= 2;
+    while (CK * 2 <= Ck && CK * 2 * KHW <= 288 && lds(CK * 2) <= (size_t)(MT == 1 ? 64 : 24) * 1024) CK *= 2;
     if (lds(CK) > kLdsLimit) return false;
     p->CK = CK;
     p->R4 = sprk::roundup(CK * KHW, 4);

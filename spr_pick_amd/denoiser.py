@@ -164,14 +164,16 @@ class Denoiser(nn.Module):
             hm = hm.to(self.device)
         model = self.models[Denoiser.MODEL]
 
-        net_out, hm_p = model(inp, eps=eps)
-        hm_p = _sigmoid(hm_p)
         if train:
             p = np.random.rand() if flip_p is None else flip_p
             axis = -1 if p <= 0.5 else -2
-            _, hm_p_f = model(inp.flip(axis), eps=eps_flip)
+            (net_out, hm_p), (_, hm_p_f) = model.forward_pair(inp, inp.flip(axis), eps, eps_flip)
+            hm_p = _sigmoid(hm_p)
             hm_p_f = _sigmoid(hm_p_f.flip(axis))
             pred_loss = self._pu(tau, hm_p, target_host)
+        else:
+            net_out, hm_p = model(inp, eps=eps)
+            hm_p = _sigmoid(hm_p)
 
         mu_x = net_out[:, 0:1]
         noise_std = self._noise_std(inp)

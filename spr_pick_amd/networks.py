@@ -545,3 +545,16 @@ class JointNetwork(nn.Module):
         out_stats = res[0] if isinstance(res, tuple) else res
         z = self.reparameterize(out_stats, eps)
         return out_stats, self.detector(z)
+
+    def forward_pair(self, x, x2, eps=None, eps2=None):
+        """Two forward passes (the training step's original and flipped batch, denoiser_v2.py:295-311)
+        with the stateless blind-spot U-Net evaluated once on the concatenated batch — twice the work
+        per kernel launch, identical results.  The detector (BatchNorm: batch statistics and running
+        averages per pass) still runs once per pass, in the reference's order."""
+        B = x.shape[0]
+        res = self.denoise_branch(torch.cat((x, x2), dim=0))
+        both = res[0] if isinstance(res, tuple) else res
+        out1, out2 = both[:B], both[B:]
+        det1 = self.detector(self.reparameterize(out1, eps))
+        det2 = self.detector(self.reparameterize(out2, eps2))
+        return (out1, det1), (out2, det2)

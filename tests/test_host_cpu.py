@@ -70,3 +70,18 @@ def test_pu_loss_matches_oracle():
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
     y2 = torch.full((16, 1), -1.0)
     assert torch.allclose(PuLoss()(0.05, p, y2), pipeline.pu_loss(0.05, p, y2), rtol=1e-5, atol=1e-6)
+
+
+def test_pick_filter_and_writer(tmp_path):
+    """N2 (train.py:563-571): border filter is strict (> 30, < size-30) and columns are (row, col)."""
+    from spr_pick_amd import picks
+    scores = np.asarray([0.9, 0.8, 0.7, 0.6, 0.5], dtype=np.float32)
+    coords = np.asarray([[50, 40], [30, 40], [31, 31], [100, 69], [69, 100]], dtype=np.int32)  # (col, row)
+    s, c = picks.filter_picks(scores, coords, (100, 140))
+    # rows must be in (30, 70), cols in (30, 110)
+    assert c.tolist() == [[50, 40], [31, 31], [100, 69]]
+    p = tmp_path / "m_scores.txt"
+    assert picks.write_scores(str(p), "mic", scores, coords, (100, 140)) == 3
+    lines = p.read_text().splitlines()
+    assert lines[0] == "image_name\tx_coord\ty_coord\tscore"
+    assert lines[1] == "mic\t40\t50\t" + str(np.float32(0.9))
