@@ -420,7 +420,7 @@ struct WgArgs {
     int CKW;                 // input channels per blockIdx.y
     int ioffN;               // ints reserved for the k-row offset table
     int inRows, inCols, pitch, cplane, colOff;
-    int xrow, g4, vec1, vec2, deal, dbg;
+    int xrow, g4, vec1, vec2, deal;
     float invImg, invPitch;
 };
 
@@ -527,13 +527,11 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
         float *x_lds = stage_base + b * stageFloats;
         float *g_lds = x_lds + a.CKW * a.cplane;
-        if (a.dbg & 1) {
-        } else if (a.xrow)
+        if (a.xrow)
             stage_rows16(x_lds, a.x, a.C1, planeI, a.Win, a.Hin, c0, cke, Cin, n0, oy0, ox0);
         else
             stage_input_dma(x_lds, src, pg, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, c0, cke, lw, lane);
-        if (a.dbg & 2) {
-        } else if (a.g4) {
+        if (a.g4) {
             stage_rows16(g_lds, a.gy, a.Cout, planeO, a.Wout, a.Hout, co0, NT * 16, a.Cout, n0, oy0, ox0);
         } else {
             for (int col = lw; col < NT * 16; col += kWgWaves) {
@@ -572,8 +570,7 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         if (tile + 1 < t_end) issue(tile + 1, bsel ^ 1);
         const float *x_lds = stage_base + bsel * stageFloats;
         const float *g_lds = x_lds + a.CKW * a.cplane + wj * (NTW * 16 * 64);   // this wave's cout rows
-        if (a.dbg & 4) {
-        } else if (myIT >= IT) {
+        if (myIT >= IT) {
             if (a.xrow)
                 wgrad_tile<IT, IT, NTW, true>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
             else
@@ -943,7 +940,7 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
     p->CK = CK;
     p->R4 = sprk::roundup(CK * KHW, 4);
     p->rows = sprk::cdiv(Ck, CK) * p->R4;
-    p->ldsBytes = std::max(lds(CK), (size_t)dbg_int("SPRK_LDS_MIN", 0));
+    p->ldsBytes = lds(CK);
     p->wsBytes = ((size_t)kZeroFloats + (size_t)p->nblkN * p->rows * p->ldw) * sizeof(float);
     return true;
 }
@@ -1012,8 +1009,8 @@ void fill_args(ConvArgs &a, const FwdPlan &p) {
     const bool geo = ((1 << p.lgTC) * a.stride) % 4 == 0 && (a.Win % 4) == 0;
     a.vec1 = (geo && !a.up1 && aligned16(a.x)) ? 1 : 0;
     a.vec2 = (geo && a.x2 && aligned16(a.x2)) ? 1 : 0;
-    a.deal = dbg_int("SPRK_DEAL", 1);
-    a.xcdRemap = dbg_int("SPRK_XCD", 1);
+    a.deal = 1;
+    a.xcdRemap = 1;
 }
 
 int transform_weights(const float *w, float *ws, int Cout, int Cin, int KHW, int mode, const FwdPlan &p,
@@ -1095,7 +1092,7 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     if (itw > 5) return false;
     p->ldsBytes = lds(CKW);
     const int per = p->nChunks * p->nblkN;
-    int groups = std::max(1, std::min(p->nTiles, sprk::cdiv(dbg_int("SPRK_WG_BLOCKS", 512), per)));  // > CU count: not every CU may be free
+    int groups = std::max(1, std::min(p->nTiles, sprk::cdiv(512, per)));  // > CU count: not every CU may be free
     p->tilesPerGroup = sprk::cdiv(p->nTiles, groups);
     p->groups = sprk::cdiv(p->nTiles, p->tilesPerGroup);
     p->wsBytes = ((size_t)kZeroFloats + (size_t)p->groups * Cin * KHW * p->CoutP) * sizeof(float);
@@ -1276,8 +1273,7 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
         const bool geo = ((1 << p.lgTC) * g->stride) % 4 == 0 && (g->Win % 4) == 0;
         a.vec1 = (geo && !g->up1 && aligned16(x)) ? 1 : 0;
         a.vec2 = (geo && x2 && aligned16(x2)) ? 1 : 0;
-        a.deal = dbg_int("SPRK_DEAL", 1);
-        a.dbg = dbg_int("SPRK_WG_DBG", 0);
+        a.deal = 1;
     }
     a.xrow = p.xrow;
     a.g4 = (p.lgTC >= 2 && (g->Wout % 4) == 0 && ((uintptr_t)gy & 15) == 0) ? 1 : 0;
