@@ -146,7 +146,7 @@ def main():
 
     import ctypes
     prof = {}
-    for kc, nm in ((0, "conv_mfma_kernel (fwd + bwd-data)"), (1, "conv_wgrad_mfma_kernel")):
+    for kc, nm in ((0, "conv_mfma_kernel<4, 6>"), (1, "conv_wgrad_mfma_kernel"), (2, "conv_mfma_kernel<other>")):
         n_, ms_, fl_ = ctypes.c_long(), ctypes.c_double(), ctypes.c_double()
         L.sprk_prof_collect(kc, ctypes.byref(n_), ctypes.byref(ms_), ctypes.byref(fl_))
         prof[kc] = (nm, n_.value, ms_.value, fl_.value)
@@ -201,8 +201,10 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                      "launches": n0, "avg_launch_ms": ms0 / max(n0, 1)},
         "whole_step_mfma_frac": value / world * FLOP_PER_PATCH_STEP / (PEAK_FP32_MFMA_TFLOPS * 1e12),
-        "wgrad_kernel": {"kernel": prof[1][0], "launches": prof[1][1], "avg_launch_ms": prof[1][2] / max(prof[1][1], 1),
-                         "achieved_tflops": prof[1][3] / (prof[1][2] * 1e-3) / 1e12 if prof[1][2] > 0 else 0.0},
+        "other_mfma_kernels": [{"kernel": prof[k][0], "launches": prof[k][1], "avg_launch_ms": prof[k][2] / max(prof[k][1], 1),
+                                "achieved_tflops": prof[k][3] / (prof[k][2] * 1e-3) / 1e12 if prof[k][2] > 0 else 0.0}
+                               for k in (1, 2)],
+        "all_conv_mfma_tflops": (prof[0][3] + prof[2][3]) / ((prof[0][2] + prof[2][2]) * 1e-3) / 1e12 if prof[0][2] > 0 else 0.0,
         "kernel_launches_per_step": launches / args.steps, "final_loss": last_loss,
     }
     if infer:

@@ -177,8 +177,9 @@ int sprk_nms2d(const float *scores, int H, int W, int r, float threshold,
 /* ---- in-library kernel timing (bench.py's roofline leg) --------------------------------
  * When enabled, every launch of the MFMA convolution kernels is bracketed by HIP events
  * on its own stream; sprk_prof_collect synchronises those events and returns, per kernel
- * class (0 = conv fwd / bwd-data MFMA, 1 = conv bwd-weight MFMA), the launch count, the
- * summed duration in ms and the summed algorithmic FLOPs. */
+ * class (0 = conv_mfma_kernel<4, 6>, the dominant forward / backward-data instantiation;
+ * 1 = conv_wgrad_mfma_kernel (all instantiations); 2 = the other conv_mfma_kernel
+ * instantiations), the launch count, the summed duration in ms and the summed algorithmic FLOPs. */
 void sprk_prof_enable(int on);
 int sprk_prof_collect(int kclass, long *launches, double *ms, double *flops);
 

@@ -1171,9 +1171,10 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
     fill_args(a, p);
     a.vec4 = (g->Wout % 4 == 0) && (p.lgTC >= 2) && (((uintptr_t)y & 15) == 0);
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * g->KH * g->KW;
-    sprk::prof_begin(0, flops, s);
+    const int kclass = (p.MT == 4 && p.NT == 6) ? 0 : 2;   // 0: the dominant instantiation conv_mfma_kernel<4, 6>
+    sprk::prof_begin(kclass, flops, s);
     if (int rc = launch_fwd(a, p, s)) return rc;
-    sprk::prof_end(0, s);
+    sprk::prof_end(kclass, s);
     return sprk::check_launch("conv_mfma");
 }
 
@@ -1219,9 +1220,10 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
     fill_args(a, p);
     a.vec4 = (g->Win % 4 == 0) && (p.lgTC >= 2) && (((uintptr_t)gin & 15) == 0);
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * g->KH * g->KW;
-    sprk::prof_begin(0, flops, s);
+    const int kclass = (p.MT == 4 && p.NT == 6) ? 0 : 2;
+    sprk::prof_begin(kclass, flops, s);
     if (int rc = launch_fwd(a, p, s)) return rc;
-    sprk::prof_end(0, s);
+    sprk::prof_end(kclass, s);
     return sprk::check_launch("conv_mfma(bwd_data)");
 }
 
