@@ -96,6 +96,7 @@ def main():
 
     rank, world, local = distributed.init_from_env()
     assert world == args.gpus, "launch with --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
+    local = local % torch.cuda.device_count()   # (== LOCAL_RANK on a real multi-GPU node)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     L = _lib.lib()
