@@ -119,6 +119,79 @@ __global__ void rot4_stack_bwd_kernel(const float *__restrict__ gy, float *__res
 }
 
 // f[b, k*C + c, i, j] = R_{a_k}( shift_down_1( d[k*B + b, c] ) )[i, j],  a = (0, 270, 180, 90)
+// 32x32 tiles through LDS: the source tile is read along its rows and the output tile written along
+// its rows (both coalesced) whatever the rotation; P is a multiple of 32 (blind-spot networks need
+// P % 32 == 0 anyway).  grid: (tiles per plane, planes), block 32x8.
+//   FWD:  out (i,j) of plane (b, k*C+c)  <- shifted source (u,v) = rot_src(a_k; i,j), value d[u-1][v] (0 if u == 0)
+//   BWD:  out (s,v) of plane (k*B+b, c)  <- gf (i,j) = rot_dst(a_k; s+1, v)                 (0 if s == P-1)
+template <bool FWD>
+__global__ __launch_bounds__(256) void unrot4_tiled_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                           int B, int C, int P) {
+    __shared__ float tile[32][33];
+    const int tilesPer = P >> 5;
+    const int ti = blockIdx.x / tilesPer, tj = blockIdx.x % tilesPer;
+    const int pl = blockIdx.y;  // output plane index
+    int k, b, c;
+    if (FWD) {
+        b = pl / (4 * C);
+        const int kc = pl - b * 4 * C;
+        k = kc / C;
+        c = kc - k * C;
+    } else {
+        k = pl / (B * C);
+        const int bc = pl - k * B * C;
+        b = bc / C;
+        c = bc - b * C;
+    }
+    const int rot = (4 - k) & 3;
+    const long plane = (long)P * P;
+    const float *src = in + (FWD ? (((long)k * B + b) * C + c) : (((long)b * 4 + k) * C + c)) * plane;
+    float *dst = out + (long)pl * plane;
+    const int o0 = ti << 5, o1 = tj << 5;  // output tile origin (row, col)
+    // source tile origin: image of the output tile's corners under the (affine) index map
+    int a0, a1, b0, b1;
+    if (FWD) {
+        rot_src(rot, o0, o1, P, a0, a1);
+        rot_src(rot, o0 + 31, o1 + 31, P, b0, b1);
+    } else {
+        rot_dst(rot, o0 + 1, o1, P, a0, a1);
+        rot_dst(rot, o0 + 32, o1 + 31, P, b0, b1);
+    }
+    const int s0 = min(a0, b0), s1 = min(a1, b1);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        // source coordinates in the shifted (FWD) / gf (BWD) plane
+        const int u = s0 + r, v = s1 + tx;
+        float val = 0.f;
+        if (FWD) {
+            if (u >= 1 && u < P && v >= 0 && v < P) val = src[(long)(u - 1) * P + v];
+        } else {
+            if (u >= 0 && u < P && v >= 0 && v < P) val = src[(long)u * P + v];
+        }
+        tile[r][tx] = val;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int i = o0 + r, j = o1 + tx;
+        int u, v;
+        float val;
+        if (FWD) {
+            rot_src(rot, i, j, P, u, v);
+            val = tile[u - s0][v - s1];
+        } else {
+            if (i + 1 < P) {
+                rot_dst(rot, i + 1, j, P, u, v);
+                val = tile[u - s0][v - s1];
+            } else {
+                val = 0.f;
+            }
+        }
+        dst[(long)i * P + j] = val;
+    }
+}
+
 __global__ void unrot4_fwd_kernel(const float *__restrict__ d, float *__restrict__ f, int B, int C, int P) {
     const long plane = (long)P * P, total = (long)B * 4 * C * plane;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -298,6 +371,11 @@ int sprk_rot4_stack_bwd(const float *gy, float *gx, int B, int C, int P, void *s
 
 int sprk_unrot4_shift_concat_fwd(const float *d, float *f, int B, int C, int P, void *stream) {
     SPRK_REQUIRE(d && f && B > 0 && C > 0 && P > 0, "unrot4_shift_concat_fwd: bad arguments");
+    if (P % 32 == 0 && (long)4 * B * C < 65536) {
+        hipLaunchKernelGGL(unrot4_tiled_kernel<true>, dim3((P / 32) * (P / 32), 4 * B * C), dim3(256), 0,
+                           (hipStream_t)stream, d, f, B, C, P);
+        return sprk::check_launch("unrot4_fwd_tiled");
+    }
     hipLaunchKernelGGL(unrot4_fwd_kernel, dim3(sprk::ew_blocks(4L * B * C * P * P)), dim3(256), 0, (hipStream_t)stream,
                        d, f, B, C, P);
     return sprk::check_launch("unrot4_fwd");
@@ -305,6 +383,11 @@ int sprk_unrot4_shift_concat_fwd(const float *d, float *f, int B, int C, int P, 
 
 int sprk_unrot4_shift_concat_bwd(const float *gf, float *gd, int B, int C, int P, void *stream) {
     SPRK_REQUIRE(gf && gd && B > 0 && C > 0 && P > 0, "unrot4_shift_concat_bwd: bad arguments");
+    if (P % 32 == 0 && (long)4 * B * C < 65536) {
+        hipLaunchKernelGGL(unrot4_tiled_kernel<false>, dim3((P / 32) * (P / 32), 4 * B * C), dim3(256), 0,
+                           (hipStream_t)stream, gf, gd, B, C, P);
+        return sprk::check_launch("unrot4_bwd_tiled");
+    }
     hipLaunchKernelGGL(unrot4_bwd_kernel, dim3(sprk::ew_blocks(4L * B * C * P * P)), dim3(256), 0, (hipStream_t)stream,
                        gf, gd, B, C, P);
     return sprk::check_launch("unrot4_bwd");
