@@ -52,6 +52,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // The first 256 floats of the workspace are zeroed: the DMA source of out-of-image lanes.
 // ------------------------------------------------------------------------------------------
 constexpr int kZeroFloats = 256;
+__device__ __attribute__((aligned(64))) float g_zero_block[kZeroFloats];  // zero-initialised; source of out-of-image DMA lanes
 
 __global__ void weight_transform_kernel(const float *__restrict__ w, float *__restrict__ ws, int Cout, int Cin,
                                         int KHW, int mode, int CK, int R4, int rows, int NT16, int ldw, int nblk) {
@@ -779,8 +780,45 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const floa
                                                       int W, int up2, int nsplit) {
     const int c = blockIdx.x, s = blockIdx.y;
     float sum = 0.f;
+    const bool al16 = (((uintptr_t)g | (uintptr_t)y | (uintptr_t)gpre) & 15) == 0;
+    const bool v4 = !up2 && (HW & 3) == 0 && al16;
+    const bool v2u = up2 && (W & 1) == 0 && al16;
     for (int n = s; n < N; n += nsplit) {
         const long base = ((long)n * C + c) * HW;
+        if (v4) {  // 16 bytes per lane
+            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
+                float4 v = *reinterpret_cast<const float4 *>(g + base + i);
+                if (act != SPRK_ACT_NONE) {
+                    const float4 yv = *reinterpret_cast<const float4 *>(y + base + i);
+                    const bool lk = act == SPRK_ACT_LEAKY;
+                    v.x = yv.x > 0.f ? v.x : (lk ? v.x * kLeak : 0.f);
+                    v.y = yv.y > 0.f ? v.y : (lk ? v.y * kLeak : 0.f);
+                    v.z = yv.z > 0.f ? v.z : (lk ? v.z * kLeak : 0.f);
+                    v.w = yv.w > 0.f ? v.w : (lk ? v.w * kLeak : 0.f);
+                    *reinterpret_cast<float4 *>(gpre + base + i) = v;
+                }
+                sum += (v.x + v.y) + (v.z + v.w);
+            }
+            continue;
+        }
+        if (v2u) {  // two outputs per lane: one float4 from each of the two source rows
+            for (int i = threadIdx.x * 2; i < HW; i += 512) {
+                const int oy = i / W, ox = i - oy * W;
+                const long q = base * 4 + (long)(2 * oy) * (2 * W) + 2 * ox;
+                const float4 a = *reinterpret_cast<const float4 *>(g + q);
+                const float4 b = *reinterpret_cast<const float4 *>(g + q + 2 * W);
+                float2 v = make_float2((a.x + a.y) + (b.x + b.y), (a.z + a.w) + (b.z + b.w));
+                if (act != SPRK_ACT_NONE) {
+                    const float4 yv = *reinterpret_cast<const float4 *>(y + q);
+                    const bool lk = act == SPRK_ACT_LEAKY;
+                    v.x = yv.x > 0.f ? v.x : (lk ? v.x * kLeak : 0.f);
+                    v.y = yv.z > 0.f ? v.y : (lk ? v.y * kLeak : 0.f);
+                }
+                *reinterpret_cast<float2 *>(gpre + base + i) = v;
+                sum += v.x + v.y;
+            }
+            continue;
+        }
         for (int i = threadIdx.x; i < HW; i += 256) {
             float v, yv = 0.f;
             if (up2) {
@@ -1254,12 +1292,13 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
         return SPRK_EWORKSPACE;
     }
     float *wsf = (float *)ws;
-    if (hipMemsetAsync(wsf, 0, kZeroFloats * sizeof(float), s) != hipSuccess) {
-        sprk::set_error("conv2d_bwd_weight: memset failed");
+    const float *zeros = nullptr;  // device-resident, never written: no per-call memset
+    if (hipGetSymbolAddress((void **)&zeros, HIP_SYMBOL(g_zero_block)) != hipSuccess || !zeros) {
+        sprk::set_error("conv2d_bwd_weight: zero block unavailable");
         return SPRK_ELAUNCH;
     }
     WgArgs a{};
-    a.x = x; a.x2 = x2; a.gy = gy; a.zeros = wsf; a.partial = wsf + kZeroFloats;
+    a.x = x; a.x2 = x2; a.gy = gy; a.zeros = zeros; a.partial = wsf + kZeroFloats;
     a.N = g->N; a.C1 = g->C1; a.C2 = g->C2; a.Hin = g->Hin; a.Win = g->Win; a.up1 = g->up1;
     a.H1 = g->up1 ? g->Hin / 2 : g->Hin;
     a.W1 = g->up1 ? g->Win / 2 : g->Win;
