@@ -158,6 +158,20 @@ int sprk_ssdn_bwd(const float *gloss, const float *x, const float *out_stats, co
                   float *g_out_stats, float *g_noise_std, int B, int HW,
                   void *ws, size_t ws_bytes, void *stream);
 
+/* ---- training-patch feed ----------------------------------------------------------------
+ * replaces MicrographDataset.__getitem__ (train branch) — datasets/micrograph.py:60-122 — plus the
+ * DataLoader collation (train.py:1085-1091): PIL crop box (x-P/2, y-P/2, x+P/2, y+P/2) with zero
+ * fill outside the image, RandomHorizontalFlip, to_tensor (uint8 -> float32/255; float images
+ * unchanged) and the CWH->CHW permute that transposes the patch:
+ *   out[b,0,u,v] = mic[image_b][y_b - P/2 + v][x_b - P/2 + (flip_b ? P-1-u : u)]
+ * mics: all micrographs packed back to back in one device buffer of `dtype`
+ * (SPRK_MIC_U8 | SPRK_MIC_F32); offsets[n_mics] (elements, device int64); dims[n_mics][2] =
+ * (rows, cols) device int32; items[B][4] = (image, x, y, flip) device int32; out [B,1,P,P]. */
+#define SPRK_MIC_U8 0
+#define SPRK_MIC_F32 1
+int sprk_gather_patches(const void *mics, int dtype, const long *offsets, const int *dims, const int *items,
+                        float *out, int n_mics, int B, int P, void *stream);
+
 /* ---- 2-D greedy non-maximum suppression ------------------------------------------------
  * replaces non_maximum_suppression(x, r, contam=set(), threshold) —
  * utils/algorithms.py:59-103, call site train.py:564.  Exact greedy semantics incl. the

@@ -59,6 +59,7 @@ _SIGS = {
     "sprk_ssdn_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_vp, c_sz, c_vp]),
     "sprk_nms2d_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "sprk_nms2d": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "sprk_gather_patches": (c_i, [c_vp, c_i, c_vp, c_vp, c_vp, c_f, c_i, c_i, c_i, c_vp]),
     "sprk_prof_enable": (None, [c_i]),
     "sprk_prof_collect": (c_i, [c_i, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
 }

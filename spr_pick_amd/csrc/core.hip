@@ -43,7 +43,7 @@ void prof_begin(int kclass, double flops, hipStream_t s) {
     }
     r.kclass = kclass;
     r.flops = flops;
-    hipEventRecord(r.a, s);
+    (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
     t_open = (int)g_recs.size() - 1;
 }
@@ -52,7 +52,7 @@ void prof_end(int kclass, hipStream_t s) {
     (void)kclass;
     if (!g_prof_on || t_open < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (t_open < (int)g_recs.size()) hipEventRecord(g_recs[t_open].b, s);
+    if (t_open < (int)g_recs.size()) (void)hipEventRecord(g_recs[t_open].b, s);
     t_open = -1;
 }
 
