@@ -1,0 +1,159 @@
+"""Device-resident data feed of the joint trainer/evaluator.
+
+Training (``PatchFeed``) replaces MicrographDataset(train=True) + DetectionDataset + the 4-worker
+DataLoader (train.py:1021-1092, datasets/micrograph.py:60-122): micrographs are uploaded to HBM
+once (uint8 when every file decodes to 8 bit, else float32), patch centres come from the
+reference's stratified sampler stream (spr_pick_amd.sampler), and each step's batch is cut out by
+``sprk_gather_patches`` (csrc/feed.hip) — PIL crop box with zero fill, horizontal flip with
+p = 0.5, to_tensor scaling and the CWH->CHW transpose.  The label of a patch is the heat-map value
+at its centre, ``hm.ravel()[coord]`` (micrograph.py:75-77).  The reference also crops hm/hm_small
+per item; no consumer reads them (denoiser_v2.py:263-272), so they are empty here.
+
+Evaluation (``MicrographFeed``) replaces MicrographDataset(train=False) + DetectionDataset padding
+(image_wrapper.py:197-249): whole micrograph -> to_tensor -> transposed [1, cols, rows] ->
+reflect-padded on the right/bottom to a multiple of 32 and to a square."""
+import numpy as np
+import torch
+
+from . import _lib, coordinates, micrograph_io, sampler as sampler_mod
+from .datasets import DetectionDataset
+
+PAD_MULTIPLE = 32     # JointNetwork.input_wh_mul()
+
+
+def load_micrographs(image_path, label_path=None, radius=3, bb=24):
+    """-> (groups, names): groups[g][i] = (image array, mask uint8, hm float32); the grouping and
+    order of MicrographDataset.load_data / match_images_targets (micrograph.py:166-292)."""
+    rows = micrograph_io.read_image_table(image_path)
+    if not rows:
+        raise ValueError("no micrographs found in %s" % image_path)
+    images = {}
+    for source, name, path in rows:
+        images.setdefault(source, {})[name] = micrograph_io.load_image(path)
+    table = coordinates.read_coordinates(label_path) if label_path else None
+    if table is not None:
+        if "source" not in table:
+            table = table.assign(source=0)
+        known = {n for grp in images.values() for n in grp}
+        table = table.loc[table.image_name.astype(str).apply(lambda n: n in known)]
+    matched = coordinates.match_coordinates_to_images(table, images, radius=radius, bb=bb)
+    groups = [list(matched[s].values()) for s in matched]
+    names = [list(matched[s].keys()) for s in matched]
+    return groups, names
+
+
+class PatchFeed:
+    """Endless stream of training batches in the DetectionDataset list layout."""
+
+    def __init__(self, groups, names, batch, patch=64, device="cuda", balance=0.1, seed=0, size=None):
+        if patch % PAD_MULTIPLE:
+            raise ValueError("patch size must be a multiple of %d" % PAD_MULTIPLE)
+        self.device = torch.device(device)
+        self.batch, self.patch = batch, patch
+        self.names = names
+        self.random = np.random.RandomState(seed)
+        self.sampler = sampler_mod.StratifiedCoordinateSampler([[m for _, m, _ in g] for g in groups],
+                                                               balance=balance, size=size, random=self.random)
+        flat = [(g, i) for g in range(len(groups)) for i in range(len(groups[g]))]
+        self._flat_id = {gi: k for k, gi in enumerate(flat)}
+        arrays = [groups[g][i][0] for g, i in flat]
+        self._hm = [groups[g][i][2].ravel() for g, i in flat]
+        self._shape = [a.shape for a in arrays]
+        all_u8 = all(a.dtype == np.uint8 for a in arrays)
+        _lib.lib()                                   # fail now, not at the first batch, if libsprk.so is missing
+        self.dtype = 0 if all_u8 else 1              # SPRK_MIC_U8 | SPRK_MIC_F32
+        if not all_u8:
+            arrays = [micrograph_io.to_unit_float(a) for a in arrays]
+        sizes = np.array([a.size for a in arrays], dtype=np.int64)
+        offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        packed = np.concatenate([np.ascontiguousarray(a).ravel() for a in arrays])
+        self.mics = torch.from_numpy(packed).to(self.device)
+        self.offsets = torch.from_numpy(offsets).to(self.device)
+        self.dims = torch.tensor([[s[0], s[1]] for s in self._shape], dtype=torch.int32, device=self.device)
+        self.n_mics = len(arrays)
+        self._items_host = torch.empty((batch, 4), dtype=torch.int32).pin_memory() if self.device.type == "cuda" \
+            else torch.empty((batch, 4), dtype=torch.int32)
+
+    def draw(self):
+        """One batch worth of sampler draws -> (items int32 [B,4] = image, x, y, flip; labels [B,1];
+        indices [B]).  Host only; the RNG order is: B sampler draws, then B flip draws."""
+        idx = [next(self.sampler) for _ in range(self.batch)]
+        flips = self.random.random_sample(self.batch) < 0.5
+        items = np.empty((self.batch, 4), dtype=np.int32)
+        labels = np.empty((self.batch, 1), dtype=np.float32)
+        for b, h in enumerate(idx):
+            g, i, coord = sampler_mod.decode_index(h)
+            k = self._flat_id[(g, i)]
+            width = self._shape[k][1]
+            items[b] = (k, coord % width, coord // width, int(flips[b]))
+            labels[b, 0] = self._hm[k][coord]
+        return items, labels, idx
+
+    def gather(self, items):
+        """items int32 [B,4] (host) -> float32 [B,1,P,P] on the device."""
+        B = items.shape[0]
+        if B == self.batch:
+            self._items_host.copy_(torch.from_numpy(items))
+            dev_items = self._items_host.to(self.device, non_blocking=True)
+        else:
+            dev_items = torch.from_numpy(np.ascontiguousarray(items)).to(self.device)
+        out = torch.empty((B, 1, self.patch, self.patch), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().sprk_gather_patches(self.mics.data_ptr(), self.dtype, self.offsets.data_ptr(),
+                                                  self.dims.data_ptr(), dev_items.data_ptr(), out.data_ptr(),
+                                                  self.n_mics, B, self.patch, stream), "sprk_gather_patches")
+        return out
+
+    def next_batch(self):
+        items, labels, idx = self.draw()
+        inp = self.gather(items)
+        flat_names = [n for grp in self.names for n in grp]
+        md = {DetectionDataset.Metadata.INDEXES: torch.tensor(idx, dtype=torch.int64),
+              DetectionDataset.Metadata.NAME: [flat_names[int(k)] for k in items[:, 0]],
+              DetectionDataset.Metadata.IMAGE_SHAPE: torch.tensor([[1, self.patch, self.patch]] * len(idx)),
+              DetectionDataset.Metadata.GT: []}
+        return DetectionDataset.make_batch(inp, torch.from_numpy(labels), metadata=md)
+
+    def __iter__(self):
+        return self
+
+    __next__ = next_batch
+
+
+def pad_to_network_size(t):
+    """[1, h, w] array -> reflect-padded (right/bottom) to a multiple of 32 and to a square."""
+    _, h, w = t.shape
+    H = (h + PAD_MULTIPLE - 1) // PAD_MULTIPLE * PAD_MULTIPLE
+    W = (w + PAD_MULTIPLE - 1) // PAD_MULTIPLE * PAD_MULTIPLE
+    H = W = max(H, W)
+    if (H, W) == (h, w):
+        return t
+    return np.pad(t, [[0, 0], [0, H - h], [0, W - w]], mode="reflect")
+
+
+class MicrographFeed:
+    """Whole micrographs for evaluation, one per batch, in dataset order (wrapping to `count`)."""
+
+    def __init__(self, groups, names, count=None, device="cuda", rank=0, world=1):
+        self.device = torch.device(device)
+        self.items = list(zip(groups[0], names[0])) if groups else []
+        if not self.items:
+            raise ValueError("empty evaluation set")
+        order = sampler_mod.sequential_indices(len(self.items), count)
+        self.order = [(pos, k) for pos, k in enumerate(order) if pos % world == rank]
+
+    def __len__(self):
+        return len(self.order)
+
+    def __iter__(self):
+        for pos, k in self.order:
+            (image, _, hm), name = self.items[k]
+            t = micrograph_io.to_unit_float(image).T[None]           # to_tensor + CWH->CHW permute
+            shape = t.shape
+            inp = torch.from_numpy(np.ascontiguousarray(pad_to_network_size(t)))[None].to(self.device)
+            md = {DetectionDataset.Metadata.INDEXES: torch.tensor([k]),
+                  DetectionDataset.Metadata.NAME: [name],
+                  DetectionDataset.Metadata.IMAGE_SHAPE: torch.tensor([list(shape)]),
+                  DetectionDataset.Metadata.GT: []}
+            hm_t = torch.from_numpy(np.ascontiguousarray(pad_to_network_size(hm.T[None])))[None]
+            yield pos, DetectionDataset.make_batch(inp, hm_t[..., :shape[1], :shape[2]], hm=hm_t, metadata=md)
