@@ -1,7 +1,8 @@
 """spr_pick_amd — MI355X-native joint denoise + particle-pick hot path of nextpyp/spr_pick.
 
 Python mirrors of the reference's plugin surface (``Denoiser``, ``JointNetwork``,
-``non_maximum_suppression``) over hand-written gfx950 kernels in libsprk.so (include/sprk.h).
+``non_maximum_suppression``) over hand-written gfx950 kernels in libsprk.so (include/sprk.h), and the
+``joint train`` / ``joint eval`` counterpart (``python -m spr_pick_amd``; train.py, eval.py, cli.py).
 """
 from . import cfg, params  # noqa: F401
 from .algorithms import nms_device, non_maximum_suppression  # noqa: F401

@@ -1,7 +1,7 @@
 """``joint`` command line (cli/cli.py, cli/cmds/train.py:24-300, cli/cmds/eval.py:15-71 of the
 reference): ``joint train start|resume`` and ``joint eval`` with the same flags and the same
 flag -> configuration mapping.  Run as ``python -m spr_pick_amd ...``; for several GPUs launch it
-under ``python -m torch.distributed.run --nproc-per-node N -m spr_pick_amd ...``."""
+under ``python -m torch.distributed.run --nproc-per-node N -m spr_pick_amd -- ...`` (keep the ``--``)."""
 import argparse
 
 from . import __version__, cfg as cfg_mod
@@ -122,6 +122,10 @@ def run_eval(args):
 
 
 def start(argv=None):
+    import sys
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if argv[:1] == ["--"]:      # `torch.distributed.run ... -m spr_pick_amd -- eval --num 8`: the separator keeps
+        argv = argv[1:]         # the launcher's own parser from prefix-matching our flags (--num ~ --numa-binding)
     parser = build_parser()
     args = vars(parser.parse_args(argv))
     if args["command"] == "train":

@@ -170,3 +170,42 @@ def test_denoise_only_mode(tmp_path):
                    % (imgs, lab, runs)).split())
     assert t.state[StateValue.ITERATION] == 32 and t.mode == "denoise"
     assert os.path.isdir(os.path.join(t.run_dir_path, "training_dn"))
+
+
+def test_two_rank_training_and_sharded_eval(tmp_path):
+    """`joint train start` under torch.distributed.run with 2 ranks (gloo rehearsal of the RCCL path on
+    one GPU): one run directory, rank-0 checkpoints, global-batch iteration counting; then a 2-rank
+    eval where micrograph i is written by rank i % 2."""
+    import socket
+    import subprocess
+    import sys
+    from spr_pick_amd import checkpoint
+    from spr_pick_amd.params import StateValue
+    imgs, lab = _write_set(str(tmp_path))
+    runs = str(tmp_path / "runs")
+    env = dict(os.environ, SPRK_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+    def launch(args):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "spr_pick_amd", "--"] + args
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+
+    launch(("train start -a ssdn -n gaussian --noise_value var -t %s -l %s -ap 0.75 -tau 0.01 -iter 64 "
+            "--train_batch_size 16 --print_interval 32 --checkpoint_interval 64 --runs_dir %s" % (imgs, lab, runs)).split())
+    assert os.listdir(runs) == ["00000-train-ssdn-gaussian-iter64-0.75-0.01-joint"]
+    run = os.path.join(runs, os.listdir(runs)[0])
+    assert sorted(os.listdir(os.path.join(run, "training_jt"))) == ["model_00000000.training", "model_00000064.training"]
+    ck = checkpoint.load(os.path.join(run, "training_jt", "model_00000064.training"))
+    assert ck["state"][StateValue.ITERATION] == 64
+    # 64 images at a global batch of 16 = 4 optimiser steps on every rank
+    assert int(next(iter(ck["optimizer"]["state"].values()))["step"]) == 4
+    launch(["eval", "-m", os.path.join(run, "final-ssdn-gaussian.wt"), "-d", imgs, "--runs_dir", runs, "--num", "2"])
+    ev = [d for d in os.listdir(runs) if "-eval-" in d]
+    assert len(ev) == 1
+    files = os.listdir(os.path.join(runs, ev[0], "eval_imgs"))
+    assert "mic0_scores.txt" in files and "mic1_scores.txt" in files
