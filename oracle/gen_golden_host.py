@@ -103,6 +103,34 @@ def main():
     d["mrc_stack_bytes"] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
     d["mrc_stack_array"] = mrc.parse(buf.getvalue())[0]
 
+    # ---- STAR / box tables ----------------------------------------------------------------
+    import pandas as pd
+    import tempfile
+    files = importlib.import_module("spr_pick.utils.files")
+    star = importlib.import_module("spr_pick.utils.star")
+    conv = importlib.import_module("spr_pick.utils.conversions")
+    star_text = ("# version 30001\n\ndata_\n\nloop_\n_rlnCoordinateX #1\n_rlnCoordinateY #2\n_rlnMicrographName #3\n"
+                 "_rlnParticleScore #4\n_rlnVoltage #5\n# a comment\n10.7\t20.2\tmicA.mrc\t0.5\t300\n\n"
+                 "33\t44.9\tsub/micB.tiff\t-1.25\t300\ndata_next\n1\t2\tmicC.mrc\t9\t1\n")
+    tmp = tempfile.mkdtemp()
+    with open(os.path.join(tmp, "p.star"), "w") as f:
+        f.write(star_text)
+    t = files.read_coordinates(os.path.join(tmp, "p.star"))
+    d["star_text"] = np.frombuffer(star_text.encode(), dtype=np.uint8)
+    d["star_columns"] = np.array(list(t.columns))
+    d["star_xy"] = t[["x_coord", "y_coord"]].values.astype(np.int64)
+    d["star_score"] = t["score"].values.astype(np.float64)
+    d["star_names"] = np.array(list(t["image_name"]))
+    with open(os.path.join(tmp, "micZ.box"), "w") as f:
+        f.write("10 20 30 40\n  5   6   7   9 extra\n")
+    b = files.read_coordinates(os.path.join(tmp, "micZ.box"))
+    d["box_xy"] = b[["x_coord", "y_coord"]].values.astype(np.int64)
+    d["box_names"] = np.array(list(b["image_name"]))
+    table = pd.DataFrame({"image_name": ["m1", "m2"], "x_coord": [3, 4], "y_coord": [5, 6], "score": [0.25, 1.5]})
+    out = io.StringIO()
+    star.write(conv.coordinates_to_star(table, image_ext=".mrc"), out)
+    d["star_written"] = np.frombuffer(out.getvalue().encode(), dtype=np.uint8)
+
     np.savez_compressed(os.path.join(OUT, "host.npz"), **d)
     print("wrote", os.path.join(OUT, "host.npz"), "with", len(d), "arrays")
 

@@ -8,7 +8,7 @@ utils/coordinates.py of the reference:
   int(gaussian_radius((bb, bb))) max-merged at every particle; the value at the sampled pixel is
   the PU-loss target of that patch.
 * ``read_coordinates`` (utils/files.py:134-171): the default tab-separated table
-  (image_name, x_coord, y_coord[, source, score]); .star/.box/.csv inputs are not built yet.
+  (image_name, x_coord, y_coord[, source, score]), RELION .star and EMAN .box; VIA .csv is not built.
 * ``match_coordinates_to_images`` (:99-154): group per source, rasterise per image.
 
 The reference also rasterises a half-resolution heat map (hm_small); nothing in the joint pipeline
@@ -76,12 +76,90 @@ def as_mask(shape, x_coord, y_coord, radii):
     return mask
 
 
+STAR_COLUMNS = {"AutopickFigureOfMerit": "score", "MicrographName": "image_name", "CoordinateX": "x_coord",
+                "CoordinateY": "y_coord", "Voltage": "voltage", "DetectorPixelSize": "detector_pixel_size",
+                "Magnification": "magnification", "AmplitudeContrast": "amplitude_contrast"}
+_STAR_FLOATS = ("AutopickFigureOfMerit", "Voltage", "DetectorPixelSize", "Magnification", "AmplitudeContrast")
+
+
+def parse_star(lines):
+    """First ``data_`` block's ``loop_`` table (utils/star.py:18-100): column names lose the ``_rln``
+    prefix and any trailing ``#k``; coordinates become int(float(.)), the known numeric columns float;
+    the old ``ParticleScore`` column is renamed to ``AutopickFigureOfMerit``."""
+    import pandas as pd
+    it = iter(range(len(lines)))
+    start = next((i for i in it if lines[i].startswith("data_")), None)
+    if start is None:
+        return None
+    lines = lines[start + 1:]
+    loop = next((i for i, l in enumerate(lines) if l.startswith("loop_")), None)
+    if loop is not None:
+        lines = lines[loop + 1:]
+    columns, k = [], 0
+    for k, raw in enumerate(lines):
+        line = raw.strip()
+        if not line.startswith("_"):
+            break
+        name = line[1:]
+        if name.find("#") >= 0:
+            name = name[:name.find("#")]
+        if name.startswith("rln"):
+            name = name[3:]
+        columns.append(name.strip())
+    content = []
+    for raw in lines[k:]:
+        line = raw.strip()
+        if line.startswith("data"):
+            break
+        if line.startswith("#") or line.startswith(";") or line == "":
+            continue
+        content.append(line.split())
+    table = pd.DataFrame(content, columns=columns)
+    if "ParticleScore" in table.columns and "AutopickFigureOfMerit" not in table.columns:
+        table["AutopickFigureOfMerit"] = table["ParticleScore"]
+        table = table.drop("ParticleScore", axis=1)
+    for c in ("CoordinateX", "CoordinateY"):
+        if c in table:
+            table[c] = table[c].astype(float).astype(int)
+    for c in _STAR_FLOATS:
+        if c in table:
+            table[c] = table[c].astype(float)
+    return table
+
+
+def boxes_to_coordinates(boxes, image_name):
+    """EMAN .box rows (x, y of the lower-left corner, width, height) -> centre coordinates
+    (utils/conversions.py:13-44, no y inversion)."""
+    import pandas as pd
+    if len(boxes) < 1:
+        return pd.DataFrame(columns=["x_coord", "y_coord", "image_name"])
+    boxes = np.asarray(boxes)
+    xy = np.stack([boxes[:, 0] + boxes[:, 2] // 2, boxes[:, 1] + boxes[:, 3] // 2], axis=1)
+    table = pd.DataFrame(xy, columns=["x_coord", "y_coord"])
+    table.insert(0, "image_name", [image_name] * len(table))
+    return table
+
+
 def read_coordinates(path):
-    """-> pandas table with image_name, x_coord, y_coord (+ source / score when present)."""
+    """-> pandas table with image_name, x_coord, y_coord (+ source / score when present)
+    (utils/files.py:134-171): .txt/.tab tab-separated table, RELION .star, EMAN .box."""
     import pandas as pd
     ext = os.path.splitext(path)[1]
-    if ext in (".star", ".box", ".json", ".csv"):
-        raise NotImplementedError("coordinate format %s is not built yet; use the tab-separated table" % ext)
+    if ext == ".star":
+        with open(path) as f:
+            table = parse_star(f.readlines())
+        for star_name, ours in STAR_COLUMNS.items():
+            if star_name in table.columns:
+                table[ours] = table[star_name]
+                table = table.drop(star_name, axis=1)
+        table["image_name"] = table["image_name"].apply(lambda n: os.path.splitext(n)[0])
+        return table
+    if ext == ".box":
+        rows = [[int(t) for t in line.split()[:4]] for line in open(path) if line.strip()]
+        return boxes_to_coordinates(np.array(rows, dtype=int).reshape(-1, 4),
+                                    os.path.basename(os.path.splitext(path)[0]))
+    if ext in (".json", ".csv"):
+        raise NotImplementedError("coordinate format %s (EMAN2 json / VIA csv) is not built" % ext)
     if ext not in (".txt", ".tab"):
         raise ValueError("Unknown coordinate file extension: %r" % ext)
     return pd.read_csv(path, sep="\t")

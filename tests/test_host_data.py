@@ -54,7 +54,7 @@ def test_coordinate_table_and_matching(tmp_path):
     _, mask_c, hm_c = m[0]["micC"]
     assert mask_c.sum() == 0 and (hm_c == -1).all()
     with pytest.raises(NotImplementedError):
-        coordinates.read_coordinates("x.star")
+        coordinates.read_coordinates("x.csv")
 
 
 # ---- sampler ----------------------------------------------------------------------------------
@@ -156,3 +156,46 @@ def test_load_image_formats(tmp_path):
     assert micrograph_io.read_image_table(str(tmp_path / "list.txt")) == [(0, "m", str(tmp_path / "m.mrc"))]
     names = sorted(n for _, n, _ in micrograph_io.read_image_table(str(tmp_path)))
     assert names == ["m", "m", "m"]
+
+
+# ---- STAR / box tables and exporters ------------------------------------------------------------
+def test_star_and_box_readers_match_reference(tmp_path):
+    p = tmp_path / "p.star"
+    p.write_bytes(GOLD["star_text"].tobytes())
+    t = coordinates.read_coordinates(str(p))
+    assert list(t.columns) == list(GOLD["star_columns"])
+    np.testing.assert_array_equal(t[["x_coord", "y_coord"]].values.astype(np.int64), GOLD["star_xy"])
+    np.testing.assert_array_equal(t["score"].values.astype(np.float64), GOLD["star_score"])
+    assert list(t["image_name"]) == list(GOLD["star_names"])
+    b = tmp_path / "micZ.box"
+    b.write_text("10 20 30 40\n  5   6   7   9 extra\n")
+    bt = coordinates.read_coordinates(str(b))
+    np.testing.assert_array_equal(bt[["x_coord", "y_coord"]].values.astype(np.int64), GOLD["box_xy"])
+    assert list(bt["image_name"]) == list(GOLD["box_names"])
+    with pytest.raises(NotImplementedError):
+        coordinates.read_coordinates("x.csv")
+    with pytest.raises(ValueError):
+        coordinates.read_coordinates("x.xyz")
+
+
+def test_star_writer_and_score_export(tmp_path):
+    import pandas as pd
+    from spr_pick_amd import export
+    table = pd.DataFrame({"image_name": ["m1", "m2"], "x_coord": [3, 4], "y_coord": [5, 6], "score": [0.25, 1.5]})
+    out = io.StringIO()
+    export.write_star(export.coordinates_to_star(table, image_ext=".mrc"), out)
+    assert out.getvalue().encode() == GOLD["star_written"].tobytes()
+    # convert_to_star.py: score > thr, strictly inside the window, x4, name = file name minus 18 chars + .mrc
+    f = tmp_path / "micA_000064_scores.txt"          # an 18-character suffix, the script's constant
+    f.write_text("image_name\tx_coord\ty_coord\tscore\nmicA\t100\t200\t0.5\nmicA\t15\t200\t0.9\nmicA\t300\t1009\t0.9\n"
+                 "micA\t16\t16\t0.13\nmicA\t17\t18\t0.131\n")
+    n = export.scores_to_star([str(f)], str(tmp_path / "o.star"))
+    text = (tmp_path / "o.star").read_text()
+    assert n == 2 and text.startswith(export.STAR_HEADER)
+    assert text[len(export.STAR_HEADER):] == "400\t800\tmicA.mrc\t0.5\n68\t72\tmicA.mrc\t0.131\n"
+    g = tmp_path / "micB_scores.txt"
+    g.write_text("image_name\tx_coord\ty_coord\tscore\nmicB\t50\t60\t0.3\n")
+    assert export.scores_to_star([str(g)], str(tmp_path / "o2.star"), strip=len("_scores.txt"), scale=1) == 1
+    assert (tmp_path / "o2.star").read_text().endswith("50\t60\tmicB.mrc\t0.3\n")
+    back = coordinates.read_coordinates(str(tmp_path / "o2.star"))          # and our reader takes it back
+    assert list(back["image_name"]) == ["micB"] and int(back["x_coord"][0]) == 50 and float(back["score"][0]) == 0.3
