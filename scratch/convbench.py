@@ -1,6 +1,6 @@
 """Micro-benchmark of the conv kernels on the hot shapes (events on the launch stream)."""
 import sys, ctypes, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from spr_pick_amd import _lib, ops
 L = _lib.lib()

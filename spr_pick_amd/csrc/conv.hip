@@ -407,8 +407,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
 // backward-weight MFMA kernel:  partial[group][k = c*KHW + tap][CoutP]
 //   D[k-row][cout] += X[k-row][pixel] * G[pixel][cout] over the block's 64-pixel tiles; both
 //   operands arrive by LDS-DMA, double buffered, so the next tile streams in under the MFMAs.
-//   The G tile is stored [cout][64 pixels] with its 16-byte chunks XOR-swizzled by (cout & 7)
-//   (applied on the DMA source address; the image itself is lane-linear) -> 2-way conflicts only.
+//   The G tile is stored [cout][64 pixels] with its 16 16-byte chunks XOR-swizzled by (cout & 15)
+//   (applied on the DMA source address; the image itself is lane-linear): the 16 couts x 4 pixels one
+//   B-operand read touches fall into 64 distinct words.
 // ------------------------------------------------------------------------------------------
 struct WgArgs {
     const float *x, *x2, *gy, *zeros;
@@ -460,7 +461,7 @@ __device__ __forceinline__ void wgrad_tile(f32x4 (&acc)[IT][NT], const float *x_
 
 // WJ = 2: eight waves (two per SIMD); wave (wi, wj) owns k-tiles wi, wi+4, ... x the wj-th half of the
 // NT cout tiles, so that one wave's LDS latency and barrier skew are covered by its SIMD partner.
-template <int IT, int NT, int WJ>
+template <int IT, int NT, int WJ, bool XROW>
 __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs a) {
     constexpr int NTW = NT / WJ;          // cout tiles per wave
     constexpr int kWgThreads = 256 * WJ;
@@ -504,14 +505,14 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
 
     const TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1, a.vec1, a.vec2};
     const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal, kWgWaves};
-    // rows of 64 pixels, 16-byte chunks XOR-swizzled by (row & 7): LDS chunk (row, qs) <- pixels
-    // 4q..4q+3, q = qs ^ (row & 7).  base: tensor [N][C][H*W]; row r is channel ch0 + r.
+    // rows of 64 pixels, 16-byte chunks XOR-swizzled by (row & 15): LDS chunk (row, qs) <- pixels
+    // 4q..4q+3, q = qs ^ (row & 15).  base: tensor [N][C][H*W]; row r is channel ch0 + r.
     auto stage_rows16 = [&](float *dst, const float *base, int C, long plane, int W, int H, int ch0, int nrows,
                             int chlim, int n0, int oy0, int ox0) {
         for (int gi = lw; gi * 4 < nrows; gi += kWgWaves) {
             const int idx = gi * 64 + lane;
             const int row = idx >> 4, qs = idx & 15;
-            const int p = (qs ^ (row & 7)) << 2;
+            const int p = (qs ^ (row & 15)) << 2;
             const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
             const int n = n0 + il, oy = oy0 + r, ox = ox0 + c, ch = ch0 + row;
             const float *s = a.zeros + lane * 4;
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
         float *x_lds = stage_base + b * stageFloats;
         float *g_lds = x_lds + a.CKW * a.cplane;
-        if (a.xrow)
+        if (XROW)
             stage_rows16(x_lds, a.x, a.C1, planeI, a.Win, a.Hin, c0, cke, Cin, n0, oy0, ox0);
         else
             stage_input_dma(x_lds, src, pg, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, c0, cke, lw, lane);
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
             stage_rows16(g_lds, a.gy, a.Cout, planeO, a.Wout, a.Hout, co0, NT * 16, a.Cout, n0, oy0, ox0);
         } else {
             for (int col = lw; col < NT * 16; col += kWgWaves) {
-                const int p = (((lane >> 2) ^ (col & 7)) << 2) | (lane & 3);
+                const int p = (((lane >> 2) ^ (col & 15)) << 2) | (lane & 3);
                 const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
                 const int n = n0 + il, oy = oy0 + r, ox = ox0 + c, co = co0 + col;
                 const float *s = a.zeros + lane;
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
     for (int t = 0; t < IT; ++t)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int gsw = l15 & 7;
+    const int gsw = l15;   // rows are multiples of 16 apart per cout tile: row & 15 == l15
     const int myIT = nIT > wi ? (nIT - wi + 3) >> 2 : 0;  // k-tiles owned by this wave (uniform)
 
     int bsel = 0;
@@ -572,21 +573,15 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         const float *x_lds = stage_base + bsel * stageFloats;
         const float *g_lds = x_lds + a.CKW * a.cplane + wj * (NTW * 16 * 64);   // this wave's cout rows
         if (myIT >= IT) {
-            if (a.xrow)
-                wgrad_tile<IT, IT, NTW, true>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
-            else
-                wgrad_tile<IT, IT, NTW, false>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
+            wgrad_tile<IT, IT, NTW, XROW>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
         } else if (IT > 1 && myIT == IT - 1) {
-            if (a.xrow)
-                wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NTW, true>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
-            else
-                wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NTW, false>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
+            wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NTW, XROW>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
         } else if (myIT > 0) {
             // short tail chunk: predicate per k-tile (rare: last channel chunk of a layer)
 #pragma unroll 2
             for (int ks = 0; ks < 16; ++ks) {
                 const int gp = ((ks ^ gsw) << 2) | lq;
-                const int xo = a.xrow ? gp : pixoff[ks * 4 + lq];
+                const int xo = XROW ? gp : pixoff[ks * 4 + lq];
                 float bv[NTW];
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) bv[nt] = g_lds[(nt * 16 + l15) * 64 + gp];
@@ -1084,7 +1079,7 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     p->nblkN = sprk::cdiv(ntile, NT);
     p->CoutP = p->nblkN * NT * 16;
     const int TM = 64;
-    int TC = std::min(sprk::pow2_ceil(g->Wout), 64);
+    int TC = std::min(sprk::pow2_ceil(g->Wout), dbg_int("SPRK_WG_TC", 64));
     if (g->dil * (g->KW - 1) >= 8) TC = std::min(TC, 8);
     int TR = std::min(TM / TC, sprk::pow2_ceil(g->Hout));
     int NI = TM / (TC * TR);
@@ -1111,49 +1106,79 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
         p->cplane = 64;
         p->colOff = 0;
     }
-    // channels per chunk: up to 20 k-tiles of 16 rows (IT = 5 per wave)
-    int CKW = std::max(1, std::min(Cin, (5 * 4 * 16) / KHW));
-    if (KHW == 9) CKW = std::min(CKW, 32);
-    if (KHW == 1) CKW = std::min(CKW, 192);
+    // channel chunks: each wave (wi = 0..3) owns k-tiles wi, wi+4, ... of a chunk's ceil(CKW*KHW/16) k-tiles, at
+    // most kMaxIT of them.  Cost of a split = chunks x busiest wave's k-tiles (+ a little per chunk for staging
+    // the G tile again); equal-sized chunks so every workgroup carries the same load.
+    constexpr int kMaxIT = 7;
     auto lds = [&](int ck) {
         const int ioffN = sprk::roundup(sprk::roundup(ck * KHW, 16), 4);
         return (size_t)(ioffN + 64 + 2 * (ck * p->cplane + NT * 16 * 64)) * 4;
     };
-    while (CKW > 1 && lds(CKW) > 150 * 1024) CKW = (CKW + 1) / 2;
-    if (lds(CKW) > kLdsLimit) return false;
+    int CKW = 0, bestCost = 1 << 30;
+    for (int nCh = 1; nCh <= Cin; ++nCh) {
+        const int ck = sprk::cdiv(Cin, nCh);
+        if (sprk::cdiv(Cin, ck) != nCh) continue;
+        const int itw = sprk::cdiv(sprk::cdiv(ck * KHW, 16), 4);
+        if (itw > kMaxIT || lds(ck) > 150 * 1024 || (p->xrow && ck > 192)) continue;
+        const int cost = nCh * (4 * itw + 1);
+        if (cost < bestCost) {
+            bestCost = cost;
+            CKW = ck;
+        }
+        if (itw == 1) break;
+    }
+    if (CKW == 0 || lds(CKW) > kLdsLimit) return false;
     p->CKW = CKW;
     p->nChunks = sprk::cdiv(Cin, CKW);
     p->ioffN = sprk::roundup(sprk::roundup(CKW * KHW, 16), 4);
-    const int nIT = sprk::cdiv(std::min(CKW, Cin) * KHW, 16);
-    const int itw = sprk::cdiv(nIT, 4);
-    p->IT = itw <= 1 ? 1 : itw <= 2 ? 2 : itw <= 3 ? 3 : 5;
-    if (itw > 5) return false;
+    p->IT = sprk::cdiv(sprk::cdiv(CKW * KHW, 16), 4);
     p->ldsBytes = lds(CKW);
+    // one workgroup per CU (the stages fill most of the LDS): never more workgroups than CUs, or the
+    // surplus runs as a second, nearly empty round
     const int per = p->nChunks * p->nblkN;
-    int groups = std::max(1, std::min(p->nTiles, sprk::cdiv(512, per)));  // > CU count: not every CU may be free
+    int groups = std::max(1, std::min(p->nTiles, dbg_int("SPRK_WG_BLOCKS", 256) / per));
     p->tilesPerGroup = sprk::cdiv(p->nTiles, groups);
     p->groups = sprk::cdiv(p->nTiles, p->tilesPerGroup);
     p->wsBytes = ((size_t)kZeroFloats + (size_t)p->groups * Cin * KHW * p->CoutP) * sizeof(float);
     return true;
 }
 
-template <int IT, int NT>
+template <int IT, int NT, bool XROW>
 int launch_wg_one(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
     constexpr int WJ = (NT % 2 == 0) ? 2 : 1;   // two waves per SIMD whenever the cout tiles split evenly
-    if (int rc = set_lds(conv_wgrad_mfma_kernel<IT, NT, WJ>, p.ldsBytes)) return rc;
-    hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, NT, WJ>), grid, dim3(256 * WJ), p.ldsBytes, s, a);
+    if (int rc = set_lds(conv_wgrad_mfma_kernel<IT, NT, WJ, XROW>, p.ldsBytes)) return rc;
+    hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, NT, WJ, XROW>), grid, dim3(256 * WJ), p.ldsBytes, s, a);
     return SPRK_OK;
 }
 
-template <int IT>
+template <int IT, bool XROW>
 int launch_wg_nt(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
     switch (p.NT) {
-        case 1: return launch_wg_one<IT, 1>(a, p, grid, s);
-        case 2: return launch_wg_one<IT, 2>(a, p, grid, s);
-        case 3: return launch_wg_one<IT, 3>(a, p, grid, s);
-        case 4: return launch_wg_one<IT, 4>(a, p, grid, s);
-        default: return launch_wg_one<IT, 6>(a, p, grid, s);
+        case 1: return launch_wg_one<IT, 1, XROW>(a, p, grid, s);
+        case 2: return launch_wg_one<IT, 2, XROW>(a, p, grid, s);
+        case 3: return launch_wg_one<IT, 3, XROW>(a, p, grid, s);
+        case 4: return launch_wg_one<IT, 4, XROW>(a, p, grid, s);
+        default: return launch_wg_one<IT, 6, XROW>(a, p, grid, s);
     }
+}
+
+template <bool XROW>
+int launch_wg(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
+    switch (p.IT) {
+        case 1: return launch_wg_nt<1, XROW>(a, p, grid, s);
+        case 2: return launch_wg_nt<2, XROW>(a, p, grid, s);
+        case 3: return launch_wg_nt<3, XROW>(a, p, grid, s);
+    }
+    if constexpr (!XROW) {   // the row-staged 1x1 form never needs more than 192 channels = 3 k-tiles per wave
+        switch (p.IT) {
+            case 4: return launch_wg_nt<4, XROW>(a, p, grid, s);
+            case 5: return launch_wg_nt<5, XROW>(a, p, grid, s);
+            case 6: return launch_wg_nt<6, XROW>(a, p, grid, s);
+            case 7: return launch_wg_nt<7, XROW>(a, p, grid, s);
+        }
+    }
+    sprk::set_error("conv2d_bwd_weight: no kernel for %d k-tiles per wave", p.IT);
+    return SPRK_EINVAL;
 }
 
 }  // namespace
@@ -1325,13 +1350,7 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     dim3 grid(p.groups, p.nChunks, p.nblkN);
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * g->KH * g->KW;
     sprk::prof_begin(1, flops, s);
-    int rc;
-    switch (p.IT) {
-        case 1: rc = launch_wg_nt<1>(a, p, grid, s); break;
-        case 2: rc = launch_wg_nt<2>(a, p, grid, s); break;
-        case 3: rc = launch_wg_nt<3>(a, p, grid, s); break;
-        default: rc = launch_wg_nt<5>(a, p, grid, s); break;
-    }
+    const int rc = p.xrow ? launch_wg<true>(a, p, grid, s) : launch_wg<false>(a, p, grid, s);
     if (rc) return rc;
     sprk::prof_end(1, s);
     if (int rc2 = sprk::check_launch("conv_wgrad_mfma")) return rc2;
