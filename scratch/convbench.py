@@ -14,6 +14,11 @@ SHAPES = {
     "head 384->384 1x1@64": (32, 384, 0, 64, 64, 0, 384, 1, (0, 0, 0, 0)),
     "head 384->96 1x1@64": (32, 384, 0, 64, 64, 0, 96, 1, (0, 0, 0, 0)),
     "dec3.0 up96+48->96@16": (128, 96, 48, 16, 16, 1, 96, 3, (2, 0, 1, 1)),
+    "cin4->96@64": (128, 4, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
+    "cin8->96@64": (128, 8, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
+    "cin16->96@64": (128, 16, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
+    "cin32->96@64": (128, 32, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
+    "cin64->96@64": (128, 64, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
 }
 which = sys.argv[1:] or list(SHAPES)
 reps = 10

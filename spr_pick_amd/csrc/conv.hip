@@ -180,6 +180,82 @@ __device__ __forceinline__ void stage_input_dma(float *in_lds, const TileSrc &s,
     }
 }
 
+// ---- buffer-addressed, table-driven staging ---------------------------------------------------------
+// Non-MFMA VALU instructions take issue time from the MFMA stream of the SIMD (measured: ~8 cycles each,
+// a quarter of a 16x16x4 fp32 MFMA), and the pointer arithmetic of stage_planes (divisions, bounds checks,
+// 64-bit multiplies, zero-block selects) was ~1.3 VALU per MFMA over a 96-channel convolution.  Here the
+// per-lane part of a DMA address is computed once per workgroup (build_xtab, a byte offset per lane and
+// 256/64-float group of a channel plane, kept in LDS) and the per-channel part is wave-uniform:
+//   buffer_load_dword[x4] voffset(table), rsrc(source tensor at the chunk's first channel), soffset(channel) lds
+// Lanes outside the image carry voffset 0x80000000: beyond num_records, the load returns 0 into LDS (checked
+// on gfx950 by scratch/buflds_test.hip; soffset is not part of the range check) — the zero fill costs nothing.
+// 0xFFFFFFFF marks lanes past the staged plane: no load at all.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int kMaxXG = 12;
+constexpr int kXZero = (int)0x80000000, kXSkip = -1;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ void bdma16(rsrc_t r, int voff, int soff, float *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds_wave_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void bdma4(rsrc_t r, int voff, int soff, float *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds_wave_base, 4, voff, soff, 0, 0);
+}
+
+__device__ __forceinline__ void build_xtab(int *tab, int nG, int vec, int up, int Ws, long imgStride, int N, int Hin,
+                                           int Win, const PlaneGeom &g, int n0, int iy0, int ixa, int tid,
+                                           int nthreads) {
+    const int imgElems = g.inRows * g.pitch;
+    const int planeElems = g.NI * imgElems;
+    for (int idx = tid; idx < nG * 64; idx += nthreads) {
+        const int gi = idx >> 6, ln = idx & 63;
+        const int e = vec ? gi * 256 + ln * 4 : gi * 64 + ln;
+        const int il = fast_div(e, g.invImg);
+        const int rem = e - il * imgElems;
+        const int r = fast_div(rem, g.invPitch);
+        const int j = rem - r * g.pitch;
+        const int n = n0 + il, iy = iy0 + r, ix = ixa + j;
+        int v = kXSkip;
+        if (e < planeElems) {
+            const bool ok = n < N && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+            v = ok ? (int)(((long)n * imgStride + (up ? (long)(iy >> 1) * Ws + (ix >> 1) : (long)iy * Ws + ix)) * 4)
+                   : kXZero;
+        }
+        tab[idx] = v;
+    }
+}
+
+// nch channel planes, channel stride csBytes, of the tensor behind `r` (based at the first staged channel)
+template <int NW>
+__device__ __forceinline__ void stage_planes_buf(float *dst, rsrc_t r, int csBytes, int nch, const int *tab, int nG,
+                                                 int vec, int cplane, int lw, int lane) {
+    int offv[kMaxXG];
+#pragma unroll
+    for (int gi = 0; gi < kMaxXG; ++gi)
+        if (gi < nG) offv[gi] = tab[gi * 64 + lane];
+    const int per = vec ? 256 : 64;
+#pragma unroll
+    for (int gi = 0; gi < kMaxXG; ++gi) {
+        if (gi >= nG) break;
+        const int o = offv[gi];
+        const int cl0 = (lw + NW - (gi % NW)) % NW;
+        float *d = dst + gi * per + cl0 * cplane;
+        int soff = cl0 * csBytes;
+        for (int cl = cl0; cl < nch; cl += NW) {
+            if (o != kXSkip) {
+                if (vec)
+                    bdma16(r, o, soff, d);
+                else
+                    bdma4(r, o, soff, d);
+            }
+            soff += NW * csBytes;
+            d += NW * cplane;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward / backward-data MFMA kernel
 // ------------------------------------------------------------------------------------------
@@ -197,6 +273,7 @@ struct ConvArgs {
     int ldw;
     int resH, resW, resOff;
     int vec4, vec1, vec2, up2, deal, xcdRemap;
+    int xtab, nG1, nG2;      // table-driven input staging: groups per plane for source 1 / source 2
     float invImg, invPitch;
 };
 
@@ -266,11 +343,13 @@ __device__ __forceinline__ void store_tile(const ConvArgs &a, const f32x4 c, int
 
 template <int MT, int NT>
 __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) {
-    // LDS: koff[2][R4] | stage 0: input[CK*cplane] weights[R4*ldw] | stage 1: ...
+    // LDS: koff[2][R4] | xtab1[nG1*64] xtab2[nG2*64] | stage 0: input[CK*cplane] weights[R4*ldw] | stage 1: ...
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int stageFloats = a.CK * a.cplane + a.R4 * a.ldw;
     int *koff_base = reinterpret_cast<int *>(smem);
-    float *stage_base = smem + 2 * a.R4;
+    int *xtab1 = koff_base + 2 * a.R4;
+    int *xtab2 = xtab1 + a.nG1 * 64;
+    float *stage_base = smem + 2 * a.R4 + (a.nG1 + a.nG2) * 64;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -338,15 +417,44 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
         }
         float *in_lds = stage_base + b * stageFloats;
         float *w_lds = in_lds + a.CK * a.cplane;
-        stage_input_dma(in_lds, src, pg, n0, iy0, ix0, c0, cke, lw, lane);
         const float *wsrc = wslab + (long)(c0 / a.CK) * a.R4 * a.ldw;
         const int total4 = (kchunk * a.ldw) >> 2;
-        for (int gi = lw; gi * 64 < total4; gi += kIssuers) {
-            const int idx = gi * 64 + lane;
-            if (idx < total4) dma16(wsrc + idx * 4, w_lds + gi * 256);
+        if (a.xtab) {
+            const int n1 = max(0, min(c0 + cke, a.C1) - c0);   // channels of this chunk taken from x
+            if (n1 > 0) {
+                const int cs1 = a.H1 * a.W1 * 4;
+                stage_planes_buf<4>(in_lds, make_rsrc(a.x + (long)c0 * (a.H1 * a.W1)), cs1, n1, xtab1, a.nG1, a.vec1,
+                                    a.cplane, lw, lane);
+            }
+            if (n1 < cke) {
+                const int cs2 = a.Hin * a.Win * 4;
+                const int cb = max(c0, a.C1) - a.C1;
+                stage_planes_buf<4>(in_lds + n1 * a.cplane, make_rsrc(a.x2 + (long)cb * (a.Hin * a.Win)), cs2, cke - n1,
+                                    xtab2, a.nG2, a.vec2, a.cplane, lw, lane);
+            }
+            const rsrc_t wr = make_rsrc(wsrc);
+            const int wv = lane * 16;
+            for (int gi = lw; gi * 64 < total4; gi += kIssuers)
+                if (gi * 64 + lane < total4) bdma16(wr, wv, gi * 1024, w_lds + gi * 256);
+        } else {
+            stage_input_dma(in_lds, src, pg, n0, iy0, ix0, c0, cke, lw, lane);
+            for (int gi = lw; gi * 64 < total4; gi += kIssuers) {
+                const int idx = gi * 64 + lane;
+                if (idx < total4) dma16(wsrc + idx * 4, w_lds + gi * 256);
+            }
         }
     };
 
+    if (a.xtab) {
+        const int ixa = ix0 - a.colOff;
+        if (a.nG1)
+            build_xtab(xtab1, a.nG1, a.vec1, a.up1, a.W1, (long)a.C1 * a.H1 * a.W1, a.N, a.Hin, a.Win, pg, n0, iy0, ixa,
+                       tid, kBlock);
+        if (a.nG2)
+            build_xtab(xtab2, a.nG2, a.vec2, 0, a.Win, (long)a.C2 * a.Hin * a.Win, a.N, a.Hin, a.Win, pg, n0, iy0, ixa,
+                       tid, kBlock);
+        __syncthreads();
+    }
     if (loader) issue(0, 0);
     int ci = 0;
     for (int c0 = 0; c0 < Cin; c0 += a.CK, ++ci) {
@@ -899,6 +1007,7 @@ struct FwdPlan {
     int MT, NT, lgTC, lgTR, tilesX, tilesY, imgGroups, nblkN;
     int CK, R4, rows;
     int inRows, inCols, pitch, cplane, colOff, ldw, NI;
+    int xtab, nG1, nG2;   // table-driven input staging (conv_mfma_kernel): groups per plane, source 1 / 2
     size_t ldsBytes, wsBytes;
 };
 
@@ -921,7 +1030,8 @@ int pick_nt(int ntile) {
 }
 
 // Ck: channels along GEMM-k; Nn: GEMM-n extent; output spatial dims Ho x Wo over Nimg images
-bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stride, int dil, int padL, FwdPlan *p) {
+bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stride, int dil, int padL, int up1,
+              int hasC2, int WinSrc, FwdPlan *p) {
     const int KHW = KH * KW;
     const int ntile = sprk::cdiv(Nn, 16);
     int NT = pick_nt(ntile);
@@ -960,10 +1070,20 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
         blocks = geometry(MT, NT);
     }
     p->ldw = (NT % 2) ? NT * 16 : NT * 16 + 16;
+    // per-tile source-offset tables (one entry per DMA lane and 256- or 64-float group of a channel plane):
+    // source 1 by 16-byte DMA, or dword DMA when it is upsampled on load; source 2 by 16-byte DMA
+    {
+        const int planeElems = p->NI * p->inRows * p->pitch;
+        const bool vecGeo = (((1 << p->lgTC) * stride) % 4 == 0) && (WinSrc % 4 == 0);
+        p->nG1 = up1 ? sprk::cdiv(planeElems, 64) : sprk::cdiv(planeElems, 256);
+        p->nG2 = hasC2 ? sprk::cdiv(planeElems, 256) : 0;
+        p->xtab = (vecGeo && p->nG1 <= kMaxXG && p->nG2 <= kMaxXG) ? 1 : 0;
+        if (!p->xtab) p->nG1 = p->nG2 = 0;
+    }
     // channels per K-chunk: two stages (double buffer) should leave room for 3 workgroups per CU
     auto lds = [&](int ck) {
         const int r4 = sprk::roundup(ck * KHW, 4);
-        return (size_t)(2 * r4 + 2 * (ck * p->cplane + r4 * p->ldw)) * 4;
+        return (size_t)(2 * r4 + (p->nG1 + p->nG2) * 64 + 2 * (ck * p->cplane + r4 * p->ldw)) * 4;
     };
     int CK = std::max(1, std::min(Ck, KHW == 1 ? 16 : std::max(1, 36 / KHW)));
     while (CK > 1 && lds(CK) > 52 * 1024) CK >>= 1;
@@ -1044,6 +1164,15 @@ void fill_args(ConvArgs &a, const FwdPlan &p) {
     a.vec2 = (geo && a.x2 && aligned16(a.x2)) ? 1 : 0;
     a.deal = 1;
     a.xcdRemap = 1;
+    // the tables hold byte offsets below 2^31 (image + in-plane part) and were sized for the expected DMA
+    // widths; a chunk's channel offset (soffset) stays below 2^32 bytes
+    const bool small1 = (long)a.N * a.C1 * a.H1 * a.W1 < (1L << 29) && (long)a.CK * a.H1 * a.W1 < (1L << 29);
+    const bool small2 = (long)a.N * a.C2 * a.Hin * a.Win < (1L << 29) && (long)a.CK * a.Hin * a.Win < (1L << 29);
+    static const int tabmode = dbg_int("SPRK_XTAB", 1);   // debug: 0 = pointer-arithmetic staging, 2 = also 1x1
+    const bool want = tabmode == 2 || (tabmode == 1 && a.KH * a.KW > 1);
+    a.xtab = (p.xtab && want && small1 && small2 && (a.up1 || a.vec1) && (a.C2 == 0 || a.vec2)) ? 1 : 0;
+    a.nG1 = p.nG1;
+    a.nG2 = p.nG2;
 }
 
 int transform_weights(const float *w, float *ws, int Cout, int Cin, int KHW, int mode, const FwdPlan &p,
@@ -1191,7 +1320,8 @@ extern "C" {
 size_t sprk_conv2d_fwd_ws_bytes(const sprk_conv_geom *g) {
     if (!g) return 0;
     FwdPlan p;
-    if (!plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, g->pad_left, &p)) return 0;
+    if (!plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, g->pad_left, g->up1,
+                  g->C2 > 0, g->Win, &p)) return 0;
     return p.wsBytes;
 }
 
@@ -1211,7 +1341,8 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
         return sprk::check_launch("conv_fwd_direct");
     }
     FwdPlan p;
-    SPRK_REQUIRE(plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, g->pad_left, &p),
+    SPRK_REQUIRE(plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, g->pad_left, g->up1,
+                  g->C2 > 0, g->Win, &p),
                  "conv2d_fwd: geometry does not fit LDS");
     if (ws_bytes < p.wsBytes || !ws) {
         sprk::set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, p.wsBytes);
@@ -1244,7 +1375,8 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
 size_t sprk_conv2d_bwd_data_ws_bytes(const sprk_conv_geom *g) {
     if (!g || g->stride != 1) return 0;
     FwdPlan p;
-    if (!plan_fwd(g->N, g->Cout, g->C1 + g->C2, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, (g->KW - 1) * g->dil - g->pad_left, &p)) return 0;
+    if (!plan_fwd(g->N, g->Cout, g->C1 + g->C2, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, (g->KW - 1) * g->dil - g->pad_left, 0, 0,
+                  g->Wout, &p)) return 0;
     return p.wsBytes;
 }
 
@@ -1263,7 +1395,8 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
     }
     // gin = correlation of gy with the flipped, channel-transposed kernel
     FwdPlan p;
-    SPRK_REQUIRE(plan_fwd(g->N, g->Cout, Cin, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, (g->KW - 1) * g->dil - g->pad_left, &p),
+    SPRK_REQUIRE(plan_fwd(g->N, g->Cout, Cin, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, (g->KW - 1) * g->dil - g->pad_left, 0, 0,
+                          g->Wout, &p),
                  "conv2d_bwd_data: geometry does not fit LDS");
     if (ws_bytes < p.wsBytes || !ws) {
         sprk::set_error("conv2d_bwd_data: workspace %zu < %zu", ws_bytes, p.wsBytes);
