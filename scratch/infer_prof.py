@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from bench import make_cfg
 from spr_pick_amd import Denoiser, DetectionDataset, nms_device, synthetic

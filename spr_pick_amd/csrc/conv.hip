@@ -31,8 +31,6 @@ constexpr int kThreads = 256;       // 4 compute waves (one per SIMD)
 // instructions at a time between the MFMAs of the running stage instead of in one burst after the barrier.
 constexpr int kLoaders = 0;
 constexpr int kBlock = kThreads + 64 * kLoaders;
-constexpr int kIssuers = kLoaders ? kLoaders : 4;          // waves that share the DMA issue
-constexpr int kIssueThreads = kLoaders ? 64 * kLoaders : kThreads;
 constexpr float kLeak = 0.1f;
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -87,6 +85,14 @@ __global__ void weight_transform_kernel(const float *__restrict__ w, float *__re
 // LDS-DMA staging (global_load_lds: HBM/L2 -> LDS without passing through VGPRs)
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void;
+// LDS addresses as plain integers: one VGPR add per operand address, immediates for the rest
+typedef const __attribute__((address_space(3))) float *lds_cfp;
+typedef const __attribute__((address_space(3))) int *lds_cip;
+__device__ __forceinline__ int lds_addr(const void *p) {
+    return (int)(unsigned)(__SIZE_TYPE__)(const __attribute__((address_space(3))) char *)p;
+}
+__device__ __forceinline__ lds_cfp lds_f(int byte_addr) { return (lds_cfp)(__SIZE_TYPE__)(unsigned)byte_addr; }
+__device__ __forceinline__ lds_cip lds_i(int byte_addr) { return (lds_cip)(__SIZE_TYPE__)(unsigned)byte_addr; }
 
 __device__ __forceinline__ void dma4(const float *src, float *lds_wave_base) {
     __builtin_amdgcn_global_load_lds(src, (lds_void *)lds_wave_base, 4, 0, 0);
@@ -220,7 +226,7 @@ __device__ __forceinline__ void build_xtab(int *tab, int nG, int vec, int up, in
         int v = kXSkip;
         if (e < planeElems) {
             const bool ok = n < N && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
-            v = ok ? (int)(((long)n * imgStride + (up ? (long)(iy >> 1) * Ws + (ix >> 1) : (long)iy * Ws + ix)) * 4)
+            v = ok ? (int)(((long)il * imgStride + (up ? (long)(iy >> 1) * Ws + (ix >> 1) : (long)iy * Ws + ix)) * 4)
                    : kXZero;
         }
         tab[idx] = v;
@@ -341,9 +347,65 @@ __device__ __forceinline__ void store_tile(const ConvArgs &a, const f32x4 c, int
     }
 }
 
-template <int MT, int NT>
+// The K loop of one staged chunk.  Non-MFMA VALU instructions take issue time from the MFMA stream (about a
+// quarter of an fp32 16x16x4 MFMA each), so a k-step is written to need few of them: all operand addresses
+// are absolute LDS byte addresses; the RB row bases of this wave's MT pixel tiles take one add each (tiles
+// of one row are 16 floats apart: immediates), the weight row one add (cout tiles: immediates), the k-row
+// offset one add for its table address.  The operands of step kq+1 are fetched under the MFMAs of step kq.
+//   abase[r]: address of this lane's pixel of row base r at channel 0, tap 0 of the stage
+//   kaddr:    address of koff[lq] (byte offsets of k rows 4kq+lq);   baddr: address of w[lq][l15]
+template <int MT, int NT, int RB>
+__device__ __forceinline__ void chunk_mma(f32x4 (&acc)[MT][NT], const int (&abase)[RB], int kaddr, int baddr,
+                                          int bstep, int nkq) {
+    constexpr int MPR = MT / RB;
+    float av[MT], bv[NT];
+    {
+        const int ko = *lds_i(kaddr);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            lds_cfp ap = lds_f(abase[r] + ko);
+#pragma unroll
+            for (int j = 0; j < MPR; ++j) av[r * MPR + j] = ap[16 * j];
+        }
+        lds_cfp bp = lds_f(baddr);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[16 * nt];
+    }
+    const int last = nkq - 1;
+    for (int kq = 0; kq < nkq; ++kq) {
+        const int kn = min(kq + 1, last);   // the last step re-reads itself (unused)
+        const int ko = lds_i(kaddr)[kn * 4];
+        float an[MT], bn[NT];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            lds_cfp ap = lds_f(abase[r] + ko);
+#pragma unroll
+            for (int j = 0; j < MPR; ++j) an[r * MPR + j] = ap[16 * j];
+        }
+        lds_cfp bp = lds_f(baddr + kn * bstep);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bn[nt] = bp[16 * nt];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = an[mt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
+    }
+}
+
+// RB: row bases per wave (1: the wave's MT pixel tiles lie in one tile row, ... MT: one base per tile).
+// XTAB: inputs staged by buffer loads through the per-tile offset tables (the normal case); the other
+// instantiation keeps the pointer-arithmetic staging for geometries the tables do not cover (rows that are
+// not 16-byte aligned).  Two kernels instead of a run-time branch: the K-chunk loop is short on scalar
+// registers, and every spilled scalar comes back through a v_readlane, i.e. a VALU instruction.
+template <int MT, int NT, int RB, bool XTAB>
 __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) {
-    // LDS: koff[2][R4] | xtab1[nG1*64] xtab2[nG2*64] | stage 0: input[CK*cplane] weights[R4*ldw] | stage 1: ...
+    // LDS: koff[2][R4] (full chunk | last chunk) | xtab1[nG1*64] xtab2[nG2*64] | stage 0: input[CK*cplane]
+    //      weights[R4*ldw] | stage 1: ...
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int stageFloats = a.CK * a.cplane + a.R4 * a.ldw;
     int *koff_base = reinterpret_cast<int *>(smem);
@@ -374,16 +436,14 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
     const int iy0 = oy0 * a.stride - a.padT, ix0 = ox0 * a.stride - a.padL;
     const int KHW = a.KH * a.KW, Cin = a.C1 + a.C2;
     const int TCm = (1 << a.lgTC) - 1, TRm = (1 << a.lgTR) - 1;
+    const int lw = wave;
 
-    const bool loader = kLoaders ? wave >= 4 : true;   // wave-uniform roles
-    const bool compute = kLoaders ? wave < 4 : true;
-    const int lw = kLoaders ? wave - 4 : wave, ltid = kLoaders ? tid - kThreads : tid;
-    int pixbase[MT];
+    int abase[RB];   // byte offset of this lane's pixel (row base r) inside a stage's input image
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int p = ((wave & 3) * MT + mt) * 16 + l15;
-        const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
-        pixbase[mt] = (il * a.inRows + r * a.stride) * a.pitch + c * a.stride + a.colOff;
+    for (int r = 0; r < RB; ++r) {
+        const int p = (wave * MT + r * (MT / RB)) * 16 + l15;
+        const int il = p >> lgT, rr = (p >> a.lgTC) & TRm, c = p & TCm;
+        abase[r] = ((il * a.inRows + rr * a.stride) * a.pitch + c * a.stride + a.colOff) * 4;
     }
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -391,61 +451,21 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1, a.vec1, a.vec2};
+    // k-row byte offsets (tap-major inside a chunk) for a full chunk and for the last, possibly shorter one
+    const int ckeLast = Cin - ((Cin - 1) / a.CK) * a.CK;
+    for (int idx = tid; idx < 2 * a.R4; idx += kBlock) {
+        const int which = idx >= a.R4, k = idx - which * a.R4;
+        const int cke = which ? ckeLast : a.CK;
+        int v = 0;
+        if (k < cke * KHW) {
+            const int tap = k / cke, cl = k - tap * cke;
+            const int ky = tap / a.KW, kx = tap - ky * a.KW;
+            v = (cl * a.cplane + (ky * a.pitch + kx) * a.dil) * 4;
+        }
+        koff_base[idx] = v;
+    }
     const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal, 4};
-    const float *wslab = a.wT + (long)nb * a.rows * a.ldw;
-    int tab_cke0 = -1, tab_cke1 = -1;
-
-    // issue the DMA of chunk starting at channel c0 into stage `b`
-    auto issue = [&](int c0, int b) {
-        const int cke = min(a.CK, Cin - c0);
-        const int kvalid = cke * KHW;
-        const int kchunk = (kvalid + 3) & ~3;
-        int *koff = koff_base + b * a.R4;
-        const int have = b ? tab_cke1 : tab_cke0;
-        if (cke != have) {
-            for (int k = ltid; k < kchunk; k += kIssueThreads) {
-                int v = 0;
-                if (k < kvalid) {
-                    const int tap = k / cke, cl = k - tap * cke;
-                    const int ky = tap / a.KW, kx = tap - ky * a.KW;
-                    v = cl * a.cplane + (ky * a.pitch + kx) * a.dil;
-                }
-                koff[k] = v;
-            }
-            if (b) tab_cke1 = cke; else tab_cke0 = cke;
-        }
-        float *in_lds = stage_base + b * stageFloats;
-        float *w_lds = in_lds + a.CK * a.cplane;
-        const float *wsrc = wslab + (long)(c0 / a.CK) * a.R4 * a.ldw;
-        const int total4 = (kchunk * a.ldw) >> 2;
-        if (a.xtab) {
-            const int n1 = max(0, min(c0 + cke, a.C1) - c0);   // channels of this chunk taken from x
-            if (n1 > 0) {
-                const int cs1 = a.H1 * a.W1 * 4;
-                stage_planes_buf<4>(in_lds, make_rsrc(a.x + (long)c0 * (a.H1 * a.W1)), cs1, n1, xtab1, a.nG1, a.vec1,
-                                    a.cplane, lw, lane);
-            }
-            if (n1 < cke) {
-                const int cs2 = a.Hin * a.Win * 4;
-                const int cb = max(c0, a.C1) - a.C1;
-                stage_planes_buf<4>(in_lds + n1 * a.cplane, make_rsrc(a.x2 + (long)cb * (a.Hin * a.Win)), cs2, cke - n1,
-                                    xtab2, a.nG2, a.vec2, a.cplane, lw, lane);
-            }
-            const rsrc_t wr = make_rsrc(wsrc);
-            const int wv = lane * 16;
-            for (int gi = lw; gi * 64 < total4; gi += kIssuers)
-                if (gi * 64 + lane < total4) bdma16(wr, wv, gi * 1024, w_lds + gi * 256);
-        } else {
-            stage_input_dma(in_lds, src, pg, n0, iy0, ix0, c0, cke, lw, lane);
-            for (int gi = lw; gi * 64 < total4; gi += kIssuers) {
-                const int idx = gi * 64 + lane;
-                if (idx < total4) dma16(wsrc + idx * 4, w_lds + gi * 256);
-            }
-        }
-    };
-
-    if (a.xtab) {
+    if (XTAB) {
         const int ixa = ix0 - a.colOff;
         if (a.nG1)
             build_xtab(xtab1, a.nG1, a.vec1, a.up1, a.W1, (long)a.C1 * a.H1 * a.W1, a.N, a.Hin, a.Win, pg, n0, iy0, ixa,
@@ -453,53 +473,68 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
         if (a.nG2)
             build_xtab(xtab2, a.nG2, a.vec2, 0, a.Win, (long)a.C2 * a.Hin * a.Win, a.N, a.Hin, a.Win, pg, n0, iy0, ixa,
                        tid, kBlock);
-        __syncthreads();
     }
-    if (loader) issue(0, 0);
+    const float *wslab = a.wT + (long)nb * a.rows * a.ldw;
+
+    // issue the DMA of the chunk starting at channel c0 into stage `b`
+    auto issue = [&](int c0, int b) {
+        const int cke = min(a.CK, Cin - c0);
+        const int kchunk = (cke * KHW + 3) & ~3;
+        float *in_lds = stage_base + b * stageFloats;
+        float *w_lds = in_lds + a.CK * a.cplane;
+        const float *wsrc = wslab + (long)(c0 / a.CK) * a.R4 * a.ldw;
+        const int total4 = (kchunk * a.ldw) >> 2;
+        if (XTAB) {
+            const int n1 = max(0, min(c0 + cke, a.C1) - c0);   // channels of this chunk taken from x
+            if (n1 > 0) {
+                const int cs1 = a.H1 * a.W1;
+                stage_planes_buf<4>(in_lds, make_rsrc(a.x + ((long)n0 * a.C1 + c0) * cs1), cs1 * 4, n1, xtab1, a.nG1,
+                                    a.vec1, a.cplane, lw, lane);
+            }
+            if (n1 < cke) {
+                const int cs2 = a.Hin * a.Win;
+                const int cb = max(c0, a.C1) - a.C1;
+                stage_planes_buf<4>(in_lds + n1 * a.cplane, make_rsrc(a.x2 + ((long)n0 * a.C2 + cb) * cs2), cs2 * 4,
+                                    cke - n1, xtab2, a.nG2, a.vec2, a.cplane, lw, lane);
+            }
+            const rsrc_t wr = make_rsrc(wsrc);
+            const int wv = lane * 16;
+            for (int gi = lw; gi * 64 < total4; gi += 4)
+                if (gi * 64 + lane < total4) bdma16(wr, wv, gi * 1024, w_lds + gi * 256);
+        } else {
+            const TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1, a.vec1, a.vec2};
+            stage_input_dma(in_lds, src, pg, n0, iy0, ix0, c0, cke, lw, lane);
+            for (int gi = lw; gi * 64 < total4; gi += 4) {
+                const int idx = gi * 64 + lane;
+                if (idx < total4) dma16(wsrc + idx * 4, w_lds + gi * 256);
+            }
+        }
+    };
+
+    __syncthreads();   // tables visible
+    issue(0, 0);
+    const int baddr0 = lds_addr(stage_base + a.CK * a.cplane + lq * a.ldw + l15);
+    const int kaddr0 = lds_addr(koff_base + lq);
+    const int abyte0 = lds_addr(stage_base);
+    const int bstep = a.ldw * 16;
     int ci = 0;
     for (int c0 = 0; c0 < Cin; c0 += a.CK, ++ci) {
         // every wave's DMA of this chunk has landed (vmcnt(0)) and every wave is done reading the
         // other stage (previous chunk) once all have passed the barrier
         __syncthreads();
-        if (loader && c0 + a.CK < Cin) issue(c0 + a.CK, (ci + 1) & 1);
-        if (!compute) continue;
-        const int b = ci & 1;
+        if (c0 + a.CK < Cin) issue(c0 + a.CK, (ci + 1) & 1);
         const int cke = min(a.CK, Cin - c0);
         const int nkq = (cke * KHW + 3) >> 2;
-        const int *koff = koff_base + b * a.R4;
-        const float *in_lds = stage_base + b * stageFloats;
-        const float *w_lds = in_lds + a.CK * a.cplane;
-        // software pipeline: the operands of step kq+1 are fetched from LDS under the MFMAs of step kq
-        float av[MT], bv[NT];
-        {
-            const int ko = koff[lq];
+        const int soff = (ci & 1) * stageFloats * 4;
+        int ab[RB];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = in_lds[pixbase[mt] + ko];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = w_lds[lq * a.ldw + nt * 16 + l15];
-        }
-        for (int kq = 0; kq < nkq; ++kq) {
-            const int krow = min(kq + 1, nkq - 1) * 4 + lq;  // the last step re-reads itself (unused)
-            const int ko = koff[krow];
-            float an[MT], bn[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) an[mt] = in_lds[pixbase[mt] + ko];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bn[nt] = w_lds[krow * a.ldw + nt * 16 + l15];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = an[mt];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = bn[nt];
-        }
+        for (int r = 0; r < RB; ++r) ab[r] = abyte0 + soff + abase[r];
+        chunk_mma<MT, NT, RB>(acc, ab, kaddr0 + (cke == a.CK ? 0 : a.R4 * 4), baddr0 + soff, bstep, nkq);
     }
 
-    if (!compute) return;  // no barrier below
     // epilogue: D layout col(n) = lane&15, row(m) = (lane>>4)*4 + reg
+    // (measured and dropped: reading the epilogue's parameters from the kernel-argument segment only here, to
+    // free scalar registers during the K loop — the private copy costs more vector registers than it frees)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int pb = (wave * MT + mt) * 16 + lq * 4;
@@ -1110,30 +1145,40 @@ int set_lds(K kernel, size_t bytes) {
     return SPRK_OK;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int RB>
 int launch_fwd_one(const ConvArgs &a, const FwdPlan &p, dim3 grid, hipStream_t s) {
-    if (int rc = set_lds(conv_mfma_kernel<MT, NT>, p.ldsBytes)) return rc;
-    hipLaunchKernelGGL((conv_mfma_kernel<MT, NT>), grid, dim3(kBlock), p.ldsBytes, s, a);
+    if (a.xtab) {
+        if (int rc = set_lds(conv_mfma_kernel<MT, NT, RB, true>, p.ldsBytes)) return rc;
+        hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, RB, true>), grid, dim3(kBlock), p.ldsBytes, s, a);
+    } else {
+        if (int rc = set_lds(conv_mfma_kernel<MT, NT, RB, false>, p.ldsBytes)) return rc;
+        hipLaunchKernelGGL((conv_mfma_kernel<MT, NT, RB, false>), grid, dim3(kBlock), p.ldsBytes, s, a);
+    }
     return SPRK_OK;
 }
 
-template <int MT>
+template <int MT, int RB>
 int launch_fwd_nt(const ConvArgs &a, const FwdPlan &p, dim3 grid, hipStream_t s) {
     switch (p.NT) {
-        case 1: return launch_fwd_one<MT, 1>(a, p, grid, s);
-        case 2: return launch_fwd_one<MT, 2>(a, p, grid, s);
-        case 3: return launch_fwd_one<MT, 3>(a, p, grid, s);
-        case 4: return launch_fwd_one<MT, 4>(a, p, grid, s);
-        default: return launch_fwd_one<MT, 6>(a, p, grid, s);
+        case 1: return launch_fwd_one<MT, 1, RB>(a, p, grid, s);
+        case 2: return launch_fwd_one<MT, 2, RB>(a, p, grid, s);
+        case 3: return launch_fwd_one<MT, 3, RB>(a, p, grid, s);
+        case 4: return launch_fwd_one<MT, 4, RB>(a, p, grid, s);
+        default: return launch_fwd_one<MT, 6, RB>(a, p, grid, s);
     }
 }
 
 int launch_fwd(const ConvArgs &a, const FwdPlan &p, hipStream_t s) {
     dim3 grid(p.imgGroups * p.tilesX * p.tilesY, p.nblkN);
+    // pixel tiles of a wave that lie in one tile row are 16 floats apart in LDS (stride 1): one address
+    // base per row instead of one per tile
+    const int rows = (a.stride == 1) ? std::max(1, (p.MT * 16) >> p.lgTC) : p.MT;
     switch (p.MT) {
-        case 1: return launch_fwd_nt<1>(a, p, grid, s);
-        case 2: return launch_fwd_nt<2>(a, p, grid, s);
-        default: return launch_fwd_nt<4>(a, p, grid, s);
+        case 1: return launch_fwd_nt<1, 1>(a, p, grid, s);
+        case 2: return rows == 1 ? launch_fwd_nt<2, 1>(a, p, grid, s) : launch_fwd_nt<2, 2>(a, p, grid, s);
+        default:
+            return rows == 1 ? launch_fwd_nt<4, 1>(a, p, grid, s)
+                             : rows == 2 ? launch_fwd_nt<4, 2>(a, p, grid, s) : launch_fwd_nt<4, 4>(a, p, grid, s);
     }
 }
 
@@ -1164,11 +1209,12 @@ void fill_args(ConvArgs &a, const FwdPlan &p) {
     a.vec2 = (geo && a.x2 && aligned16(a.x2)) ? 1 : 0;
     a.deal = 1;
     a.xcdRemap = 1;
-    // the tables hold byte offsets below 2^31 (image + in-plane part) and were sized for the expected DMA
-    // widths; a chunk's channel offset (soffset) stays below 2^32 bytes
-    const bool small1 = (long)a.N * a.C1 * a.H1 * a.W1 < (1L << 29) && (long)a.CK * a.H1 * a.W1 < (1L << 29);
-    const bool small2 = (long)a.N * a.C2 * a.Hin * a.Win < (1L << 29) && (long)a.CK * a.Hin * a.Win < (1L << 29);
-    static const int tabmode = dbg_int("SPRK_XTAB", 1);   // debug: 0 = pointer-arithmetic staging, 2 = also 1x1
+    // the tables hold byte offsets (image within the tile's group + in-plane part) below 2^31 and were sized
+    // for the expected DMA widths; a chunk's channel offset (soffset) stays below 2^32 bytes
+    const long NIm1 = p.NI - 1;
+    const bool small1 = (NIm1 * a.C1 + 1) * a.H1 * a.W1 < (1L << 29) && (long)a.CK * a.H1 * a.W1 < (1L << 29);
+    const bool small2 = (NIm1 * a.C2 + 1) * a.Hin * a.Win < (1L << 29) && (long)a.CK * a.Hin * a.Win < (1L << 29);
+    static const int tabmode = dbg_int("SPRK_XTAB", 2);   // debug: 0 = pointer-arithmetic staging, 1 = not for 1x1
     const bool want = tabmode == 2 || (tabmode == 1 && a.KH * a.KW > 1);
     a.xtab = (p.xtab && want && small1 && small2 && (a.up1 || a.vec1) && (a.C2 == 0 || a.vec2)) ? 1 : 0;
     a.nG1 = p.nG1;
