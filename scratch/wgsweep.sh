@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for blocks in 256 512; do
-  echo "== BLOCKS=$blocks"
-  SPRK_WG_BLOCKS=$blocks python3 scratch/convbench.py 2>&1 | grep GFLOP
+for m in 0 1 2; do
+  echo "== WG_XTAB=$m"
+  SPRK_WG_XTAB=$m python3 scratch/convbench.py 2>&1 | grep GFLOP | grep -v cin | sed 's/.*| bw/bw/'
 done

@@ -615,24 +615,48 @@ struct WgArgs {
     int ioffN;               // ints reserved for the k-row offset table
     int inRows, inCols, pitch, cplane, colOff;
     int xrow, g4, vec1, vec2, deal;
+    int xtab;                // buffer-load staging of the row tiles (G, and x for 1x1)
     float invImg, invPitch;
 };
 
-// one 64-pixel tile: 16 k-steps of MFMAs on NIT k-tiles x NT cout-tiles.  Branch free and software
-// pipelined by hand: the LDS operands of step ks+1 are fetched into a second register set before the
-// MFMAs of step ks are issued (with one wave per SIMD nothing else hides the LDS latency).
-template <int NIT, int IT, int NT, bool XROW>
-__device__ __forceinline__ void wgrad_tile(f32x4 (&acc)[IT][NT], const float *x_lds, const float *g_lds,
-                                           const int *pixoff, const int (&ioffv)[IT], int l15, int lq, int gsw) {
-    // (g_lds already points at this wave's first cout row)
+// one 64-pixel tile: 16 k-steps of MFMAs on NIT k-tiles x NT cout-tiles, software pipelined by hand: the LDS
+// operands of step ks+1 are fetched into a second register set before the MFMAs of step ks are issued.
+// Operand addresses are absolute LDS byte addresses and cost as few VALU instructions as possible (each one
+// takes issue time from the MFMA stream):
+//   MODE 2 (stride-1 tiles, rows of >= 4 pixels): A operand of k-tile t at  ab[t] + 16*ks  — an immediate —
+//          where ab[t] is re-based once per tile row (rowd[s]: byte delta of tile row s against a straight run);
+//   MODE 1 (1x1: the x tile is staged as swizzled 64-pixel rows like the G tile);
+//   MODE 0 (any stride): pixel offsets from the pixoff table, one add per k-tile and step.
+//   B operand: swizzled G row of this lane's cout:  gaddr + ((ks ^ gsw) << 4) + nt * 4096.
+template <int NIT, int IT, int NT, int MODE>
+__device__ __forceinline__ void wgrad_tile(f32x4 (&acc)[IT][NT], int xaddr, const int (&ioffb)[IT], int gaddr,
+                                           lds_cip pixoffp, lds_cip rowdp, int lgTC, int gsw, int lq) {
     float a0[NIT], b0[NT], a1[NIT], b1[NT];
+    int ab[NIT];
+    if (MODE == 2) {
+        const int d0 = rowdp[0];
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) ab[t] = xaddr + ioffb[t] + d0;
+    }
+    const int TCm = (1 << lgTC) - 1;
     auto load = [&](int ks, float (&av)[NIT], float (&bv)[NT]) {
-        const int gp = ((ks ^ gsw) << 2) | lq;
-        const int xo = XROW ? gp : pixoff[ks * 4 + lq];
+        const int gq = (ks ^ gsw) << 4;
+        if (MODE == 2) {
+            if (ks > 0 && ((ks * 4) & TCm) == 0) {   // next tile row (wave-uniform; never for 64-pixel rows)
+                const int d = rowdp[(ks * 4) >> lgTC];
 #pragma unroll
-        for (int t = 0; t < NIT; ++t) av[t] = x_lds[ioffv[t] + xo];
+                for (int t = 0; t < NIT; ++t) ab[t] = xaddr + ioffb[t] + d;
+            }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = g_lds[(nt * 16 + l15) * 64 + gp];
+            for (int t = 0; t < NIT; ++t) av[t] = lds_f(ab[t])[ks * 4];
+        } else {
+            const int xo = MODE == 1 ? (gq | (lq << 2)) : pixoffp[ks * 4 + lq];
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) av[t] = *lds_f(xaddr + ioffb[t] + xo);
+        }
+        lds_cfp gp = lds_f(gaddr + gq);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = gp[nt * 1024];
     };
     auto mma = [&](const float (&av)[NIT], const float (&bv)[NT]) {
 #pragma unroll
@@ -651,17 +675,25 @@ __device__ __forceinline__ void wgrad_tile(f32x4 (&acc)[IT][NT], const float *x_
     }
 }
 
+// (Measured and dropped for this kernel: staging the x planes through per-tile offset tables and buffer
+// loads as conv_mfma_kernel does — here the tile moves every 64 pixels, the per-tile validity pass costs more
+// VALU than the pointer arithmetic it replaces.  The row tiles (G, and x for 1x1) do use buffer loads.)
+
 // WJ = 2: eight waves (two per SIMD); wave (wi, wj) owns k-tiles wi, wi+4, ... x the wj-th half of the
 // NT cout tiles, so that one wave's LDS latency and barrier skew are covered by its SIMD partner.
-template <int IT, int NT, int WJ, bool XROW>
+// MODE: operand addressing of wgrad_tile (1 also means: x is staged as rows, 1x1 convolutions only).
+template <int IT, int NT, int WJ, int MODE>
 __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs a) {
+    constexpr bool XROW = MODE == 1;
     constexpr int NTW = NT / WJ;          // cout tiles per wave
     constexpr int kWgThreads = 256 * WJ;
     constexpr int kWgWaves = 4 * WJ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int *ioff = reinterpret_cast<int *>(smem);          // [ioffN]
-    int *pixoff = ioff + a.ioffN;                       // [64]
-    float *stage_base = smem + a.ioffN + 64;            // 2 x { x[CKW*cplane], g[NT*16*64] }
+    // LDS: ioff[ioffN] | pixoff[64] | rowd[16] | 2 x { x, g }
+    int *ioff = reinterpret_cast<int *>(smem);
+    int *pixoff = ioff + a.ioffN;
+    int *rowd = pixoff + 64;
+    float *stage_base = smem + a.ioffN + 64 + 16;
     const int stageFloats = a.CKW * a.cplane + NT * 16 * 64;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -686,17 +718,31 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         if (k < kvalid) {
             const int tap = k / cke, cl = k - tap * cke;
             const int ky = tap / a.KW, kx = tap - ky * a.KW;
-            v = cl * a.cplane + (ky * a.pitch + kx) * a.dil;
+            v = (cl * a.cplane + (ky * a.pitch + kx) * a.dil) * 4;   // bytes
         }
         ioff[k] = v;
     }
     if (tid < 64) {
         const int il = tid >> lgT, r = (tid >> a.lgTC) & TRm, c = tid & TCm;
-        pixoff[tid] = (il * a.inRows + r * a.stride) * a.pitch + c * a.stride + a.colOff;
+        const int off = (il * a.inRows + r * a.stride) * a.pitch + c * a.stride + a.colOff;
+        pixoff[tid] = off * 4;   // bytes
+        // byte delta of the tile row holding pixel `tid` against a straight 4-bytes-per-pixel run from pixel 0
+        if (c == 0) rowd[tid >> a.lgTC] = (off - tid) * 4;
     }
-
-    const TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1, a.vec1, a.vec2};
     const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal, kWgWaves};
+    // G rows (and, for 1x1, x rows): lane -> (row within the item's 4 rows, swizzled 16-byte chunk) -> pixel
+    const int rowl = lane >> 4;
+    int gpk, gvo, xvo;
+    {
+        const int rsw = ((lw & 3) << 2) | rowl;             // (row & 15) of every item this wave stages
+        const int p = ((lane & 15) ^ rsw) << 2;
+        const int il = p >> lgT, r = (p >> a.lgTC) & TRm, c = p & TCm;
+        gpk = (il << 20) | (r << 10) | c;
+        gvo = (int)((((long)il * a.Cout + rowl) * planeO + (long)r * a.Wout + c) * 4);
+        xvo = (int)((((long)il * a.C1 + rowl) * planeI + (long)r * a.Win + c) * 4);
+    }
+    const TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1, a.vec1, a.vec2};
+
     // rows of 64 pixels, 16-byte chunks XOR-swizzled by (row & 15): LDS chunk (row, qs) <- pixels
     // 4q..4q+3, q = qs ^ (row & 15).  base: tensor [N][C][H*W]; row r is channel ch0 + r.
     auto stage_rows16 = [&](float *dst, const float *base, int C, long plane, int W, int H, int ch0, int nrows,
@@ -712,6 +758,19 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
             if (row < nrows) dma16(s, dst + gi * 256);
         }
     };
+    // the same through buffer loads: the pixel part of the address is this lane's fixed offset against the
+    // tile origin (vo), made invalid (zero fill) per tile; the channel part is wave-uniform
+    auto stage_rows_buf = [&](float *dst, const float *base, int C, long plane, int W, int ch0, int nrows, int chlim,
+                              int n0, int oy0, int ox0, int vo, bool inside) {
+        const rsrc_t r = make_rsrc(base + ((long)n0 * C + ch0) * plane + (long)oy0 * W + ox0);
+        const int v = inside ? vo : kXZero;
+        const int rowBytes4 = (int)(plane * 16);
+        for (int gi = lw; gi * 4 < nrows; gi += kWgWaves) {
+            int vv = v;
+            if (ch0 + gi * 4 + 3 >= chlim) vv = (ch0 + gi * 4 + rowl < chlim) ? v : kXZero;   // ragged last cout block
+            if (gi * 4 + rowl < nrows) bdma16(r, vv, gi * rowBytes4, dst + gi * 256);
+        }
+    };
     auto issue = [&](int tile, int b) {
         int t = tile;
         const int tx = t % a.tilesX;
@@ -721,11 +780,22 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
         float *x_lds = stage_base + b * stageFloats;
         float *g_lds = x_lds + a.CKW * a.cplane;
-        if (XROW)
-            stage_rows16(x_lds, a.x, a.C1, planeI, a.Win, a.Hin, c0, cke, Cin, n0, oy0, ox0);
-        else
+        bool inside = false;
+        if (a.xtab) {
+            const int r = (gpk >> 10) & 1023, c = gpk & 1023, il = gpk >> 20;
+            inside = n0 + il < a.N && oy0 + r < a.Hout && ox0 + c < a.Wout;
+        }
+        if (XROW) {
+            if (a.xtab)
+                stage_rows_buf(x_lds, a.x, a.C1, planeI, a.Win, c0, cke, Cin, n0, oy0, ox0, xvo, inside);
+            else
+                stage_rows16(x_lds, a.x, a.C1, planeI, a.Win, a.Hin, c0, cke, Cin, n0, oy0, ox0);
+        } else {
             stage_input_dma(x_lds, src, pg, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, c0, cke, lw, lane);
-        if (a.g4) {
+        }
+        if (a.g4 && a.xtab) {
+            stage_rows_buf(g_lds, a.gy, a.Cout, planeO, a.Wout, co0, NT * 16, a.Cout, n0, oy0, ox0, gvo, inside);
+        } else if (a.g4) {
             stage_rows16(g_lds, a.gy, a.Cout, planeO, a.Wout, a.Hout, co0, NT * 16, a.Cout, n0, oy0, ox0);
         } else {
             for (int col = lw; col < NT * 16; col += kWgWaves) {
@@ -742,13 +812,13 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
 
     const int t_begin = blockIdx.x * a.tilesPerGroup;
     const int t_end = min(a.nTiles, t_begin + a.tilesPerGroup);
-    if (t_begin < t_end) issue(t_begin, 0);
     __syncthreads();  // tables visible
-    int ioffv[IT];
+    if (t_begin < t_end) issue(t_begin, 0);
+    int ioffb[IT];   // byte offset of this lane's k row (k-tile t) inside a stage's x image (+ its pixel quad)
 #pragma unroll
     for (int t = 0; t < IT; ++t) {
         const int it = wi + 4 * t;
-        ioffv[t] = it < nIT ? ioff[it * 16 + l15] : 0;
+        ioffb[t] = (it < nIT ? ioff[it * 16 + l15] : 0) + (MODE == 2 ? lq * 4 : 0);
     }
     f32x4 acc[IT][NTW];
 #pragma unroll
@@ -757,30 +827,33 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int gsw = l15;   // rows are multiples of 16 apart per cout tile: row & 15 == l15
     const int myIT = nIT > wi ? (nIT - wi + 3) >> 2 : 0;  // k-tiles owned by this wave (uniform)
+    const int xaddr0 = lds_addr(stage_base);
+    const int gaddr0 = lds_addr(stage_base + a.CKW * a.cplane + wj * (NTW * 16 * 64) + l15 * 64 + lq);
+    const lds_cip pixoffp = lds_i(lds_addr(pixoff)), rowdp = lds_i(lds_addr(rowd));
 
     int bsel = 0;
     for (int tile = t_begin; tile < t_end; ++tile, bsel ^= 1) {
         __syncthreads();  // this tile landed everywhere; previous tile fully consumed
         if (tile + 1 < t_end) issue(tile + 1, bsel ^ 1);
-        const float *x_lds = stage_base + bsel * stageFloats;
-        const float *g_lds = x_lds + a.CKW * a.cplane + wj * (NTW * 16 * 64);   // this wave's cout rows
+        const int soff = bsel * stageFloats * 4;
+        const int xaddr = xaddr0 + soff, gaddr = gaddr0 + soff;
         if (myIT >= IT) {
-            wgrad_tile<IT, IT, NTW, XROW>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
+            wgrad_tile<IT, IT, NTW, MODE>(acc, xaddr, ioffb, gaddr, pixoffp, rowdp, a.lgTC, gsw, lq);
         } else if (IT > 1 && myIT == IT - 1) {
-            wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NTW, XROW>(acc, x_lds, g_lds, pixoff, ioffv, l15, lq, gsw);
+            wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NTW, MODE>(acc, xaddr, ioffb, gaddr, pixoffp, rowdp, a.lgTC, gsw, lq);
         } else if (myIT > 0) {
             // short tail chunk: predicate per k-tile (rare: last channel chunk of a layer)
 #pragma unroll 2
             for (int ks = 0; ks < 16; ++ks) {
-                const int gp = ((ks ^ gsw) << 2) | lq;
-                const int xo = XROW ? gp : pixoff[ks * 4 + lq];
+                const int gq = (ks ^ gsw) << 4;
+                const int xo = MODE == 1 ? (gq | (lq << 2)) : MODE == 2 ? pixoffp[ks * 4] : pixoffp[ks * 4 + lq];
                 float bv[NTW];
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) bv[nt] = g_lds[(nt * 16 + l15) * 64 + gp];
+                for (int nt = 0; nt < NTW; ++nt) bv[nt] = lds_f(gaddr + gq)[nt * 1024];
 #pragma unroll
                 for (int t = 0; t < IT; ++t) {
                     if (t < myIT) {
-                        const float av = x_lds[ioffv[t] + xo];
+                        const float av = *lds_f(xaddr + ioffb[t] + xo);
 #pragma unroll
                         for (int nt = 0; nt < NTW; ++nt)
                             acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[nt], acc[t][nt], 0, 0, 0);
@@ -1292,6 +1365,7 @@ struct WgPlan {
     int IT, NT, lgTC, lgTR, tilesX, tilesY, nTiles, tilesPerGroup, groups;
     int CKW, nChunks, nblkN, ioffN, CoutP;
     int inRows, inCols, pitch, cplane, colOff, xrow;
+    int mode;
     size_t ldsBytes, wsBytes;
 };
 
@@ -1334,9 +1408,11 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     // most kMaxIT of them.  Cost of a split = chunks x busiest wave's k-tiles (+ a little per chunk for staging
     // the G tile again); equal-sized chunks so every workgroup carries the same load.
     constexpr int kMaxIT = 7;
+    // operand addressing of the tile loop: 1 = 1x1 rows, 2 = stride-1 tiles with rows of >= 4 pixels, 0 = any
+    p->mode = p->xrow ? 1 : (g->stride == 1 && TC >= 4) ? 2 : 0;
     auto lds = [&](int ck) {
         const int ioffN = sprk::roundup(sprk::roundup(ck * KHW, 16), 4);
-        return (size_t)(ioffN + 64 + 2 * (ck * p->cplane + NT * 16 * 64)) * 4;
+        return (size_t)(ioffN + 64 + 16 + 2 * (ck * p->cplane + NT * 16 * 64)) * 4;
     };
     int CKW = 0, bestCost = 1 << 30;
     for (int nCh = 1; nCh <= Cin; ++nCh) {
@@ -1367,38 +1443,38 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     return true;
 }
 
-template <int IT, int NT, bool XROW>
+template <int IT, int NT, int MODE>
 int launch_wg_one(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
     constexpr int WJ = (NT % 2 == 0) ? 2 : 1;   // two waves per SIMD whenever the cout tiles split evenly
-    if (int rc = set_lds(conv_wgrad_mfma_kernel<IT, NT, WJ, XROW>, p.ldsBytes)) return rc;
-    hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, NT, WJ, XROW>), grid, dim3(256 * WJ), p.ldsBytes, s, a);
+    if (int rc = set_lds(conv_wgrad_mfma_kernel<IT, NT, WJ, MODE>, p.ldsBytes)) return rc;
+    hipLaunchKernelGGL((conv_wgrad_mfma_kernel<IT, NT, WJ, MODE>), grid, dim3(256 * WJ), p.ldsBytes, s, a);
     return SPRK_OK;
 }
 
-template <int IT, bool XROW>
+template <int IT, int MODE>
 int launch_wg_nt(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
     switch (p.NT) {
-        case 1: return launch_wg_one<IT, 1, XROW>(a, p, grid, s);
-        case 2: return launch_wg_one<IT, 2, XROW>(a, p, grid, s);
-        case 3: return launch_wg_one<IT, 3, XROW>(a, p, grid, s);
-        case 4: return launch_wg_one<IT, 4, XROW>(a, p, grid, s);
-        default: return launch_wg_one<IT, 6, XROW>(a, p, grid, s);
+        case 1: return launch_wg_one<IT, 1, MODE>(a, p, grid, s);
+        case 2: return launch_wg_one<IT, 2, MODE>(a, p, grid, s);
+        case 3: return launch_wg_one<IT, 3, MODE>(a, p, grid, s);
+        case 4: return launch_wg_one<IT, 4, MODE>(a, p, grid, s);
+        default: return launch_wg_one<IT, 6, MODE>(a, p, grid, s);
     }
 }
 
-template <bool XROW>
+template <int MODE>
 int launch_wg(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
     switch (p.IT) {
-        case 1: return launch_wg_nt<1, XROW>(a, p, grid, s);
-        case 2: return launch_wg_nt<2, XROW>(a, p, grid, s);
-        case 3: return launch_wg_nt<3, XROW>(a, p, grid, s);
+        case 1: return launch_wg_nt<1, MODE>(a, p, grid, s);
+        case 2: return launch_wg_nt<2, MODE>(a, p, grid, s);
+        case 3: return launch_wg_nt<3, MODE>(a, p, grid, s);
     }
-    if constexpr (!XROW) {   // the row-staged 1x1 form never needs more than 192 channels = 3 k-tiles per wave
+    if constexpr (MODE != 1) {   // the row-staged 1x1 form never needs more than 192 channels = 3 k-tiles per wave
         switch (p.IT) {
-            case 4: return launch_wg_nt<4, XROW>(a, p, grid, s);
-            case 5: return launch_wg_nt<5, XROW>(a, p, grid, s);
-            case 6: return launch_wg_nt<6, XROW>(a, p, grid, s);
-            case 7: return launch_wg_nt<7, XROW>(a, p, grid, s);
+            case 4: return launch_wg_nt<4, MODE>(a, p, grid, s);
+            case 5: return launch_wg_nt<5, MODE>(a, p, grid, s);
+            case 6: return launch_wg_nt<6, MODE>(a, p, grid, s);
+            case 7: return launch_wg_nt<7, MODE>(a, p, grid, s);
         }
     }
     sprk::set_error("conv2d_bwd_weight: no kernel for %d k-tiles per wave", p.IT);
@@ -1570,6 +1646,15 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
         a.deal = 1;
     }
     a.xrow = p.xrow;
+    {
+        // buffer-load staging of the row tiles: 32-bit byte offsets inside one tile group and one channel block
+        const long planeI = (long)g->Hin * g->Win, planeO = (long)g->Hout * g->Wout;
+        const int NIw = 64 >> (p.lgTC + p.lgTR);
+        const bool fits = (long)NIw * Cin * planeI < (1L << 28) && (long)NIw * g->Cout * planeO < (1L << 28) &&
+                          (long)p.CKW * planeI < (1L << 28) && (long)p.NT * 16 * planeO < (1L << 28);
+        static const int rowbuf = dbg_int("SPRK_WG_ROWBUF", 1);
+        a.xtab = (rowbuf && fits) ? 1 : 0;
+    }
     a.g4 = (p.lgTC >= 2 && (g->Wout % 4) == 0 && ((uintptr_t)gy & 15) == 0) ? 1 : 0;
     if (a.xrow && (((uintptr_t)x & 15) != 0)) {
         sprk::set_error("conv2d_bwd_weight: x must be 16-byte aligned");
@@ -1578,7 +1663,7 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     dim3 grid(p.groups, p.nChunks, p.nblkN);
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * g->KH * g->KW;
     sprk::prof_begin(1, flops, s);
-    const int rc = p.xrow ? launch_wg<true>(a, p, grid, s) : launch_wg<false>(a, p, grid, s);
+    const int rc = p.mode == 1 ? launch_wg<1>(a, p, grid, s) : p.mode == 2 ? launch_wg<2>(a, p, grid, s) : launch_wg<0>(a, p, grid, s);
     if (rc) return rc;
     sprk::prof_end(1, s);
     if (int rc2 = sprk::check_launch("conv_wgrad_mfma")) return rc2;
