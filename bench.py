@@ -186,7 +186,7 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            traffic = json.load(f)["kernels"]["conv_mfma_kernel"]["hbm_bytes_per_launch"]
+            traffic = json.load(f)["kernels"]["conv_mfma_kernel<4, 6>"]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     out = {
@@ -198,7 +198,8 @@ def main():
                                "tau 0.01, Adam; fp32 MFMA convolutions" % args.batch,
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "patch": 64,
                    "parallelism": "dp%d (flat fp32 grad all-reduce, %d floats)" % (world, sync.numel()) if world > 1 else "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": nm, "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": nm, "kernel_note": "all <MT=4, NT=6, row bases, staging> instantiations",
+                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                      "launches": n0, "avg_launch_ms": ms0 / max(n0, 1)},
         "whole_step_mfma_frac": value / world * FLOP_PER_PATCH_STEP / (PEAK_FP32_MFMA_TFLOPS * 1e12),

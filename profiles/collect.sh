@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collect the round's profile artefacts on the GPU box (run from the repo root through gpurun):
+#   bash profiles/collect.sh r01
+# runs the bench plain, under the kernel trace and under three PMC passes, then profiles/summarize.py on the
+# databases; gpurun_out/prof_<tag>/summary/ holds the files to copy into profiles/.
+# (PMC passes are separate runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes.)
+set -e
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+python3 $R/bench.py --steps 10 --warmup 3 --cpu-seconds 12 > $OUT/bench.log 2>&1
+grep '^{"metric"' $OUT/bench.log > $OUT/bench.json
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --infer-size 0"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
+grep '^{"metric"' $OUT/trace.log > $OUT/bench_under_rocprof.json
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d $OUT/mfma -o m -- python3 $R/bench.py $ARGS > $OUT/mfma.log 2>&1
+mkdir -p $OUT/summary
+python3 $R/profiles/summarize.py $OUT $TAG $OUT/summary
+rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma
+ls $OUT/summary

@@ -1,0 +1,89 @@
+"""Turn the rocprofv3 databases written by profiles/collect.sh into the committed summaries:
+  <tag>_bench_kernel_stats.csv   per-kernel calls / total / average duration (kernel trace)
+  <tag>_hbm_traffic.json         per-kernel HBM bytes per launch from FETCH_SIZE (x2 on gfx950 for wide
+                                 streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE, separate PMC passes
+  <tag>_mfma_counters.json       per-kernel SQ_INSTS_VALU / SQ_INSTS_MFMA / MFMA busy cycles
+usage: python profiles/summarize.py gpurun_out/prof_r01 r01 [outdir]   (collect.sh runs it on the GPU box and keeps
+only the summaries: the databases are tens of MB)
+"""
+import collections
+import csv
+import json
+import os
+import re
+import sqlite3
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+here = sys.argv[3] if len(sys.argv) > 3 else os.path.dirname(os.path.abspath(__file__))   # output directory
+
+
+def db(sub):
+    d = os.path.join(src, sub)
+    f = [x for x in os.listdir(d) if x.endswith(".db")][0]
+    return sqlite3.connect(os.path.join(d, f))
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name)
+
+
+def family(name):
+    """conv_mfma_kernel<4, 6, 1, true> -> conv_mfma_kernel<4, 6> (all row-base / staging instantiations)."""
+    m = re.match(r"(conv_mfma_kernel)<(\d+), (\d+),", name)
+    if m:
+        return "%s<%s, %s>" % m.groups()
+    m = re.match(r"(conv_wgrad_mfma_kernel)<", name)
+    return m.group(1) if m else name
+
+
+rows = list(db("trace").execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                                "from kernels group by name order by 3 desc"))
+total = sum(r[2] for r in rows)
+with open(os.path.join(here, tag + "_bench_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+    for n, c, t, a, mn, mx in rows:
+        w.writerow([short(n), c, t, "%.1f" % a, "%.3f" % (100.0 * t / total), mn, mx])
+    fam = collections.OrderedDict()
+    for n, c, t, a, mn, mx in rows:
+        k = family(short(n))
+        if k != short(n):
+            e = fam.setdefault(k, [0, 0])
+            e[0] += c
+            e[1] += t
+    w.writerow([])
+    w.writerow(["# families (all template instantiations of one tile shape)"])
+    for k, (c, t) in fam.items():
+        w.writerow([k, c, t, "%.1f" % (t / c), "%.3f" % (100.0 * t / total), "", ""])
+
+
+def counters(sub):
+    out = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for k, cn, v in db(sub).execute("select kernel_name, counter_name, value from counters_collection"):
+        e = out[family(short(k))][cn]
+        e[0] += v
+        e[1] += 1
+    return out
+
+
+fetch, write = counters("fetch"), counters("write")
+traffic = {}
+for k in sorted(set(fetch) | set(write)):
+    fk = fetch.get(k, {}).get("FETCH_SIZE", [0.0, 1])
+    wk = write.get(k, {}).get("WRITE_SIZE", [0.0, 1])
+    fkb, wkb = fk[0] / max(fk[1], 1), wk[0] / max(wk[1], 1)
+    traffic[k] = {"launches": int(max(fk[1], wk[1])), "FETCH_SIZE_KB_avg": fkb, "WRITE_SIZE_KB_avg": wkb,
+                  "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0}
+json.dump({"note": "per-launch averages over the profiled bench run; FETCH_SIZE doubled (gfx950 counts 128-B "
+                   "requests at 64 B for wide streaming reads), WRITE_SIZE as is; separate PMC passes",
+           "kernels": traffic}, open(os.path.join(here, tag + "_hbm_traffic.json"), "w"), indent=1)
+
+mf = counters("mfma")
+json.dump({k: {cn: {"sum": v[0], "launches": v[1]} for cn, v in d.items()} for k, d in mf.items()
+           if "conv" in k}, open(os.path.join(here, tag + "_mfma_counters.json"), "w"), indent=1)
+for name in ("bench.json", "bench_under_rocprof.json"):
+    open(os.path.join(here, "%s_%s" % (tag, name)), "w").write(open(os.path.join(src, name)).read())
+print("wrote summaries for", tag)
