@@ -42,6 +42,7 @@ class FlatGradAllReduce:
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self._flat = None
         self._live = None
+        self._views = None
 
     def _select(self):
         live = [p for p in self.params if p.grad is not None]
@@ -50,6 +51,7 @@ class FlatGradAllReduce:
             n = sum(p.grad.numel() for p in live)
             self._flat = torch.empty(n, dtype=live[0].grad.dtype, device=live[0].grad.device) if live else None
             self._live, self._sig = live, sig
+            self._views = None
         return self._live
 
     def numel(self):
@@ -61,18 +63,21 @@ class FlatGradAllReduce:
         live = self._select()
         if not live:
             return
-        off = 0
-        views = []
-        for p in live:
-            n = p.grad.numel()
-            v = self._flat[off:off + n]
-            v.copy_(p.grad.reshape(-1))
-            views.append(v)
-            off += n
+        if self._views is None:
+            off, self._views = 0, []
+            for p in live:
+                n = p.grad.numel()
+                self._views.append(self._flat[off:off + n])
+                off += n
+        # two multi-tensor copies instead of one small kernel per parameter on each side of the collective
+        grads = [p.grad.reshape(-1) for p in live]
+        torch._foreach_copy_(self._views, grads)
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
         self._flat.mul_(1.0 / self.world)
-        for p, v in zip(live, views):
-            p.grad.copy_(v.view_as(p.grad))
+        torch._foreach_copy_(grads, self._views)
+        for p, g in zip(live, grads):
+            if g.data_ptr() != p.grad.data_ptr():      # non-contiguous gradient: reshape(-1) made a copy
+                p.grad.copy_(g.view_as(p.grad))
 
 
 def shard_indices(n_items, rank, world):
