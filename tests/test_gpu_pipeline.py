@@ -272,3 +272,80 @@ def test_training_reduces_loss_and_is_deterministic(oracle_state):
     l2, p2 = run()
     assert all(np.isfinite(l1)) and l1[-1] < l1[0]
     assert l1 == l2 and torch.equal(p1, p2)
+
+
+# ---- size-independent properties at BASELINE's full sizes ------------------------------
+def test_full_batch_directional_derivative(oracle_state):
+    """configs[1] (batch 32, 64x64 patches): the gradient the backward kernels produce predicts the change of
+    the loss along a random parameter direction,  (L(w + h d) - L(w - h d)) / 2h  ~=  <grad, d>.
+    The fixed eps / flip draws make L a deterministic function of w."""
+    from spr_pick_amd import Denoiser, DetectionDataset, synthetic
+    from spr_pick_amd.params import PipelineOutput as P
+    den = Denoiser(make_cfg(), device="cuda:0", mode="joint")
+    den.load_state_dict({"models." + k: v for k, v in oracle_state.items()}, strict=False)
+    den.train()
+    mics = [synthetic.micrograph(i) for i in range(4)]
+    inp, tgt = synthetic.patch_batches(1, 32, mics, device="cuda:0")[0]
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    eps = torch.randn(inp.shape, device="cuda", generator=gen)
+    eps_f = torch.randn(inp.shape, device="cuda", generator=gen)
+    # BatchNorm running statistics change on every training pass; they do not enter the training-mode loss
+    params = [p for n, p in den.named_parameters() if n.startswith("models.") and p.requires_grad]
+
+    def loss():
+        o = den.run_pipeline(DetectionDataset.make_batch(inp, tgt), 0.75, 0.01, train=True, eps=eps, eps_flip=eps_f,
+                             flip_p=0.3)
+        return torch.mean(o[P.LOSS])
+
+    L0 = loss()
+    grads = torch.autograd.grad(L0, params, allow_unused=True)
+    live = [(p, g) for p, g in zip(params, grads) if g is not None]
+    assert len(live) >= 90   # 12 of the parameter tensors never receive a gradient (SURVEY.md §8a A12)
+    dirs = [torch.randn(p.shape, device="cuda", generator=gen) * p.detach().abs().mean().clamp_min(1e-3)
+            for p, _ in live]
+    pred = float(sum((g.double() * d.double()).sum() for (_, g), d in zip(live, dirs)))
+    vals = {}
+    for h in (2e-3, 1e-3):
+        with torch.no_grad():
+            for (p, _), d in zip(live, dirs):
+                p.add_(d, alpha=h)
+            lp = float(loss())
+            for (p, _), d in zip(live, dirs):
+                p.add_(d, alpha=-2 * h)
+            lm = float(loss())
+            for (p, _), d in zip(live, dirs):
+                p.add_(d, alpha=h)
+        vals[h] = (lp - lm) / (2 * h)
+    # central differences in fp32 over ~50 layers: a few % (LeakyReLU kinks, rounding of L ~ 40 at h ~ 1e-3)
+    assert abs(vals[1e-3] - pred) <= 0.05 * abs(pred) + 1e-3, (pred, vals)
+    assert abs(vals[2e-3] - pred) <= 0.08 * abs(pred) + 1e-3, (pred, vals)
+
+
+def test_filled_inference_is_translation_consistent(oracle_state):
+    """configs[2]-style whole-micrograph inference: the filled network is a stack of convolutions and 2x2
+    poolings, so the score map and the denoised image of a crop (offsets a multiple of 32 = 2^5 pooling
+    levels) agree with the full micrograph's away from the crop's border — whatever tiles, chunks and
+    workgroup shapes the planner picked for the two sizes."""
+    from spr_pick_amd import Denoiser, DetectionDataset, synthetic
+    from spr_pick_amd.params import PipelineOutput as P
+    den = Denoiser(make_cfg(), device="cuda:0", mode="joint")
+    den.load_state_dict({"models." + k: v for k, v in oracle_state.items()}, strict=False)
+    den.eval()
+    den.fill()
+    S, C, off = 2048, 1024, 512
+    img = torch.from_numpy(synthetic.micrograph(3, size=S)[0].astype(np.float32) / 255.0).cuda()[None, None]
+    crop = img[:, :, off:off + C, off:off + C].contiguous()
+    with torch.no_grad():
+        full = den.run_pipeline(DetectionDataset.make_batch(img, torch.zeros(1, 1)), train=False,
+                                eps=torch.zeros_like(img))
+        part = den.run_pipeline(DetectionDataset.make_batch(crop, torch.zeros(1, 1)), train=False,
+                                eps=torch.zeros_like(crop))
+    m = 448   # beyond the receptive field of the 5-level blind-spot U-Net + detector (pad 31)
+    for key in (P.IMG_MU, P.DETECT):
+        a = full[key][0, 0, off + m:off + C - m, off + m:off + C - m]
+        b = part[key][0, 0, m:C - m, m:C - m]
+        scale = float(a.abs().max())
+        worst = float((a - b).abs().max())
+        print(key, "max |diff| %.3e of scale %.3e; bitwise equal: %s" % (worst, scale, bool(torch.equal(a, b))))
+        assert worst <= 2e-5 * scale + 1e-7, key
+    den.unfill()
