@@ -681,10 +681,14 @@ __device__ __forceinline__ void wgrad_tile(f32x4 (&acc)[IT][NT], int xaddr, cons
 
 // WJ = 2: eight waves (two per SIMD); wave (wi, wj) owns k-tiles wi, wi+4, ... x the wj-th half of the
 // NT cout tiles, so that one wave's LDS latency and barrier skew are covered by its SIMD partner.
-// MODE: operand addressing of wgrad_tile (1 also means: x is staged as rows, 1x1 convolutions only).
+// MODE: operand addressing of wgrad_tile.  1 (1x1 convolutions: x staged as rows) and 2 also mean that the row
+// tiles are staged by buffer loads (16-byte aligned rows, 32-bit offsets: the host checks); 0 is the general
+// form with pointer-arithmetic staging.  Separate instantiations rather than run-time branches: spilled scalar
+// registers come back as v_readlane, i.e. VALU instructions in the tile loop.
 template <int IT, int NT, int WJ, int MODE>
 __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs a) {
     constexpr bool XROW = MODE == 1;
+    constexpr bool FAST = MODE != 0;
     constexpr int NTW = NT / WJ;          // cout tiles per wave
     constexpr int kWgThreads = 256 * WJ;
     constexpr int kWgWaves = 4 * WJ;
@@ -781,19 +785,16 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         float *x_lds = stage_base + b * stageFloats;
         float *g_lds = x_lds + a.CKW * a.cplane;
         bool inside = false;
-        if (a.xtab) {
+        if (FAST) {
             const int r = (gpk >> 10) & 1023, c = gpk & 1023, il = gpk >> 20;
             inside = n0 + il < a.N && oy0 + r < a.Hout && ox0 + c < a.Wout;
         }
         if (XROW) {
-            if (a.xtab)
-                stage_rows_buf(x_lds, a.x, a.C1, planeI, a.Win, c0, cke, Cin, n0, oy0, ox0, xvo, inside);
-            else
-                stage_rows16(x_lds, a.x, a.C1, planeI, a.Win, a.Hin, c0, cke, Cin, n0, oy0, ox0);
+            stage_rows_buf(x_lds, a.x, a.C1, planeI, a.Win, c0, cke, Cin, n0, oy0, ox0, xvo, inside);
         } else {
             stage_input_dma(x_lds, src, pg, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, c0, cke, lw, lane);
         }
-        if (a.g4 && a.xtab) {
+        if (FAST) {
             stage_rows_buf(g_lds, a.gy, a.Cout, planeO, a.Wout, co0, NT * 16, a.Cout, n0, oy0, ox0, gvo, inside);
         } else if (a.g4) {
             stage_rows16(g_lds, a.gy, a.Cout, planeO, a.Wout, a.Hout, co0, NT * 16, a.Cout, n0, oy0, ox0);
@@ -1646,24 +1647,25 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
         a.deal = 1;
     }
     a.xrow = p.xrow;
-    {
-        // buffer-load staging of the row tiles: 32-bit byte offsets inside one tile group and one channel block
-        const long planeI = (long)g->Hin * g->Win, planeO = (long)g->Hout * g->Wout;
-        const int NIw = 64 >> (p.lgTC + p.lgTR);
-        const bool fits = (long)NIw * Cin * planeI < (1L << 28) && (long)NIw * g->Cout * planeO < (1L << 28) &&
-                          (long)p.CKW * planeI < (1L << 28) && (long)p.NT * 16 * planeO < (1L << 28);
-        static const int rowbuf = dbg_int("SPRK_WG_ROWBUF", 1);
-        a.xtab = (rowbuf && fits) ? 1 : 0;
-    }
     a.g4 = (p.lgTC >= 2 && (g->Wout % 4) == 0 && ((uintptr_t)gy & 15) == 0) ? 1 : 0;
-    if (a.xrow && (((uintptr_t)x & 15) != 0)) {
-        sprk::set_error("conv2d_bwd_weight: x must be 16-byte aligned");
+    // buffer-load staging of the row tiles needs 16-byte aligned rows and 32-bit byte offsets inside one tile
+    // group and one channel block; otherwise the general kernel (MODE 0) runs
+    const long planeI = (long)g->Hin * g->Win, planeO = (long)g->Hout * g->Wout;
+    const int NIw = 64 >> (p.lgTC + p.lgTR);
+    const bool fits = (long)NIw * Cin * planeI < (1L << 28) && (long)NIw * g->Cout * planeO < (1L << 28) &&
+                      (long)p.CKW * planeI < (1L << 28) && (long)p.NT * 16 * planeO < (1L << 28);
+    static const int rowbuf = dbg_int("SPRK_WG_ROWBUF", 1);
+    const bool fast = rowbuf && fits && a.g4;
+    a.xtab = fast ? 1 : 0;
+    if (a.xrow && (!fast || (((uintptr_t)x & 15) != 0))) {
+        sprk::set_error("conv2d_bwd_weight: 1x1 row staging needs 16-byte aligned x / gy and < 2^28-element tiles");
         return SPRK_EINVAL;
     }
+    const int mode = fast ? p.mode : 0;
     dim3 grid(p.groups, p.nChunks, p.nblkN);
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * g->KH * g->KW;
     sprk::prof_begin(1, flops, s);
-    const int rc = p.mode == 1 ? launch_wg<1>(a, p, grid, s) : p.mode == 2 ? launch_wg<2>(a, p, grid, s) : launch_wg<0>(a, p, grid, s);
+    const int rc = mode == 1 ? launch_wg<1>(a, p, grid, s) : mode == 2 ? launch_wg<2>(a, p, grid, s) : launch_wg<0>(a, p, grid, s);
     if (rc) return rc;
     sprk::prof_end(1, s);
     if (int rc2 = sprk::check_launch("conv_wgrad_mfma")) return rc2;
