@@ -621,57 +621,88 @@ struct WgArgs {
 
 // one 64-pixel tile: 16 k-steps of MFMAs on NIT k-tiles x NT cout-tiles, software pipelined by hand: the LDS
 // operands of step ks+1 are fetched into a second register set before the MFMAs of step ks are issued.
+// The reduced dimension of this GEMM is the pixel, so which pixel feeds which (k-step, k-lane) slot is free as
+// long as both operands agree:  k-step 4j+s, k-lane lq  <-  pixel 16j + 4lq + s.  Then the four G values a lane
+// needs for steps 4j..4j+3 are one 16-byte chunk of its cout row: one ds_read_b128 per cout tile and 4 steps
+// instead of four ds_read_b32, and the 8 lanes a b128 read serves per cycle hit 8 different swizzled chunks (no
+// bank conflicts; the per-step b32 form was 2-way conflicted).
 // Operand addresses are absolute LDS byte addresses and cost as few VALU instructions as possible (each one
 // takes issue time from the MFMA stream):
-//   MODE 2 (stride-1 tiles, rows of >= 4 pixels): A operand of k-tile t at  ab[t] + 16*ks  — an immediate —
-//          where ab[t] is re-based once per tile row (rowd[s]: byte delta of tile row s against a straight run);
+//   MODE 2 (stride-1 tiles, rows of >= 4 pixels): A operand of k-tile t at  ab[t] + 4*(16j+s)  — an immediate —
+//          where ab[t] is re-based per 16-pixel group from rowd (byte delta of a tile row against a straight run);
 //   MODE 1 (1x1: the x tile is staged as swizzled 64-pixel rows like the G tile);
 //   MODE 0 (any stride): pixel offsets from the pixoff table, one add per k-tile and step.
-//   B operand: swizzled G row of this lane's cout:  gaddr + ((ks ^ gsw) << 4) + nt * 4096.
-template <int NIT, int IT, int NT, int MODE>
+//   B operand: chunk ((4j+lq) ^ gsw) of the swizzled G row of this lane's cout, + nt * 4096 bytes.
+template <int NIT, int IT, int NT, int MODE, bool DB>
 __device__ __forceinline__ void wgrad_tile(f32x4 (&acc)[IT][NT], int xaddr, const int (&ioffb)[IT], int gaddr,
                                            lds_cip pixoffp, lds_cip rowdp, int lgTC, int gsw, int lq) {
-    float a0[NIT], b0[NT], a1[NIT], b1[NT];
+    typedef const __attribute__((address_space(3))) f32x4 *lds_c4p;
+    float a0[NIT], a1[NIT];
+    f32x4 b0[NT], b1[DB ? NT : 1];   // DB: a second G register set (workgroups with one wave per SIMD)
     int ab[NIT];
-    if (MODE == 2) {
-        const int d0 = rowdp[0];
+    const int lsw = lq ^ gsw;
+    auto loadB = [&](int j, f32x4 (&bv)[NT]) {
+        const int q = ((4 * j) ^ lsw) << 4;
 #pragma unroll
-        for (int t = 0; t < NIT; ++t) ab[t] = xaddr + ioffb[t] + d0;
-    }
-    const int TCm = (1 << lgTC) - 1;
-    auto load = [&](int ks, float (&av)[NIT], float (&bv)[NT]) {
-        const int gq = (ks ^ gsw) << 4;
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = *(lds_c4p)(__SIZE_TYPE__)(unsigned)(gaddr + q + nt * 4096);
+    };
+    auto baseA = [&](int j) {   // MODE 2: row base of this lane's 4-pixel chunk of group j
+        if (MODE == 2 && (j == 0 || lgTC < 6)) {
+            const int d = rowdp[(16 * j + 4 * lq) >> lgTC];
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) ab[t] = xaddr + ioffb[t] + d;
+        }
+    };
+    auto loadA = [&](int j, int sx, float (&av)[NIT]) {
         if (MODE == 2) {
-            if (ks > 0 && ((ks * 4) & TCm) == 0) {   // next tile row (wave-uniform; never for 64-pixel rows)
-                const int d = rowdp[(ks * 4) >> lgTC];
 #pragma unroll
-                for (int t = 0; t < NIT; ++t) ab[t] = xaddr + ioffb[t] + d;
-            }
-#pragma unroll
-            for (int t = 0; t < NIT; ++t) av[t] = lds_f(ab[t])[ks * 4];
+            for (int t = 0; t < NIT; ++t) av[t] = lds_f(ab[t])[16 * j + sx];
         } else {
-            const int xo = MODE == 1 ? (gq | (lq << 2)) : pixoffp[ks * 4 + lq];
+            const int xo = MODE == 1 ? ((((4 * j) ^ lsw) << 4) + 4 * sx) : pixoffp[16 * j + 4 * lq + sx];
 #pragma unroll
             for (int t = 0; t < NIT; ++t) av[t] = *lds_f(xaddr + ioffb[t] + xo);
         }
-        lds_cfp gp = lds_f(gaddr + gq);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = gp[nt * 1024];
     };
-    auto mma = [&](const float (&av)[NIT], const float (&bv)[NT]) {
+    auto mma = [&](const float (&av)[NIT], const f32x4 (&bv)[NT], int sx) {
 #pragma unroll
         for (int t = 0; t < NIT; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[nt], acc[t][nt], 0, 0, 0);
+                acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[nt][sx], acc[t][nt], 0, 0, 0);
     };
-    load(0, a0, b0);
+    loadB(0, b0);
+    baseA(0);
+    loadA(0, 0, a0);
 #pragma unroll
-    for (int ks = 0; ks < 16; ks += 2) {
-        load(ks + 1, a1, b1);
-        mma(a0, b0);
-        if (ks + 2 < 16) load(ks + 2, a0, b0);
-        mma(a1, b1);
+    for (int j = 0; j < 4; ++j) {
+        if constexpr (DB) {
+            if (j + 1 < 4) {
+                if (j & 1) loadB(j + 1, b0); else loadB(j + 1, b1);
+            }
+        }
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx) {
+            const int ks = 4 * j + sx;
+            if (ks + 1 < 16) {            // A operands of the next step
+                const int jn = (ks + 1) >> 2, sn = (ks + 1) & 3;
+                if (sn == 0) baseA(jn);
+                if (ks & 1) loadA(jn, sn, a0); else loadA(jn, sn, a1);
+            }
+            if constexpr (DB) {
+                if (ks & 1) {
+                    if (j & 1) mma(a1, b1, sx); else mma(a1, b0, sx);
+                } else {
+                    if (j & 1) mma(a0, b1, sx); else mma(a0, b0, sx);
+                }
+            } else {
+                if (ks & 1) mma(a1, b0, sx); else mma(a0, b0, sx);
+            }
+        }
+        // eight-wave workgroups: the G chunk of the next four steps goes into the same registers (a second set
+        // does not fit next to 84 accumulators at two waves per SIMD; the SIMD partner covers the wait)
+        if constexpr (!DB) {
+            if (j + 1 < 4) loadB(j + 1, b0);
+        }
     }
 }
 
@@ -819,7 +850,7 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
 #pragma unroll
     for (int t = 0; t < IT; ++t) {
         const int it = wi + 4 * t;
-        ioffb[t] = (it < nIT ? ioff[it * 16 + l15] : 0) + (MODE == 2 ? lq * 4 : 0);
+        ioffb[t] = (it < nIT ? ioff[it * 16 + l15] : 0) + (MODE == 2 ? lq * 16 : 0);
     }
     f32x4 acc[IT][NTW];
 #pragma unroll
@@ -829,7 +860,7 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
     const int gsw = l15;   // rows are multiples of 16 apart per cout tile: row & 15 == l15
     const int myIT = nIT > wi ? (nIT - wi + 3) >> 2 : 0;  // k-tiles owned by this wave (uniform)
     const int xaddr0 = lds_addr(stage_base);
-    const int gaddr0 = lds_addr(stage_base + a.CKW * a.cplane + wj * (NTW * 16 * 64) + l15 * 64 + lq);
+    const int gaddr0 = lds_addr(stage_base + a.CKW * a.cplane + wj * (NTW * 16 * 64) + l15 * 64);
     const lds_cip pixoffp = lds_i(lds_addr(pixoff)), rowdp = lds_i(lds_addr(rowd));
 
     int bsel = 0;
@@ -839,18 +870,21 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         const int soff = bsel * stageFloats * 4;
         const int xaddr = xaddr0 + soff, gaddr = gaddr0 + soff;
         if (myIT >= IT) {
-            wgrad_tile<IT, IT, NTW, MODE>(acc, xaddr, ioffb, gaddr, pixoffp, rowdp, a.lgTC, gsw, lq);
+            wgrad_tile<IT, IT, NTW, MODE, WJ == 1>(acc, xaddr, ioffb, gaddr, pixoffp, rowdp, a.lgTC, gsw, lq);
         } else if (IT > 1 && myIT == IT - 1) {
-            wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NTW, MODE>(acc, xaddr, ioffb, gaddr, pixoffp, rowdp, a.lgTC, gsw, lq);
+            wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NTW, MODE, WJ == 1>(acc, xaddr, ioffb, gaddr, pixoffp, rowdp, a.lgTC, gsw,
+                                                                      lq);
         } else if (myIT > 0) {
-            // short tail chunk: predicate per k-tile (rare: last channel chunk of a layer)
-#pragma unroll 2
+            // short tail chunk: predicate per k-tile (rare: last channel chunk of a layer); same pixel order
+#pragma unroll 1
             for (int ks = 0; ks < 16; ++ks) {
-                const int gq = (ks ^ gsw) << 4;
-                const int xo = MODE == 1 ? (gq | (lq << 2)) : MODE == 2 ? pixoffp[ks * 4] : pixoffp[ks * 4 + lq];
+                const int j = ks >> 2, sx = ks & 3;
+                const int q = ((4 * j) ^ lq ^ gsw) << 4;
+                const int p = 16 * j + 4 * lq + sx;
+                const int xo = MODE == 1 ? q + 4 * sx : MODE == 2 ? (16 * j + sx) * 4 + rowdp[p >> a.lgTC] : pixoffp[p];
                 float bv[NTW];
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) bv[nt] = lds_f(gaddr + gq)[nt * 1024];
+                for (int nt = 0; nt < NTW; ++nt) bv[nt] = lds_f(gaddr + q + 4 * sx)[nt * 1024];
 #pragma unroll
                 for (int t = 0; t < IT; ++t) {
                     if (t < myIT) {
