@@ -14,6 +14,10 @@ SHAPES = {
     "head 384->384 1x1@64": (32, 384, 0, 64, 64, 0, 384, 1, (0, 0, 0, 0)),
     "head 384->96 1x1@64": (32, 384, 0, 64, 64, 0, 96, 1, (0, 0, 0, 0)),
     "dec3.0 up96+48->96@16": (128, 96, 48, 16, 16, 1, 96, 3, (2, 0, 1, 1)),
+    "det32->32@29 valid": (32, 32, 0, 29, 29, 0, 32, 3, (0, 0, 0, 0)),
+    "det64->64@9 valid": (32, 64, 0, 9, 9, 0, 64, 3, (0, 0, 0, 0)),
+    "enc48->48@4": (256, 48, 0, 4, 4, 0, 48, 3, (2, 0, 1, 1)),
+    "enc48->48@8": (256, 48, 0, 8, 8, 0, 48, 3, (2, 0, 1, 1)),
     "cin4->96@64": (128, 4, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
     "cin8->96@64": (128, 8, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
     "cin16->96@64": (128, 16, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
@@ -21,7 +25,7 @@ SHAPES = {
     "cin64->96@64": (128, 64, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
 }
 which = sys.argv[1:] or list(SHAPES)
-reps = 10
+reps = 20
 for name in which:
     N, C1, C2, H, W, up1, Cout, K, pad = SHAPES[name]
     h1, w1 = (H // 2, W // 2) if up1 else (H, W)

@@ -233,31 +233,27 @@ __device__ __forceinline__ void build_xtab(int *tab, int nG, int vec, int up, in
     }
 }
 
-// nch channel planes, channel stride csBytes, of the tensor behind `r` (based at the first staged channel)
+// nch channel planes, channel stride csBytes, of the tensor behind `r` (based at the first staged channel).
+// A plain loop over the groups with the table entry read where it is used: a register array of entries costs
+// more (initialisation, guarded reads, indexed register access) than the LDS latency it hides.
 template <int NW>
 __device__ __forceinline__ void stage_planes_buf(float *dst, rsrc_t r, int csBytes, int nch, const int *tab, int nG,
                                                  int vec, int cplane, int lw, int lane) {
-    int offv[kMaxXG];
-#pragma unroll
-    for (int gi = 0; gi < kMaxXG; ++gi)
-        if (gi < nG) offv[gi] = tab[gi * 64 + lane];
     const int per = vec ? 256 : 64;
-#pragma unroll
-    for (int gi = 0; gi < kMaxXG; ++gi) {
-        if (gi >= nG) break;
-        const int o = offv[gi];
+    for (int gi = 0; gi < nG; ++gi) {
+        const int o = tab[gi * 64 + lane];
         const int cl0 = (lw + NW - (gi % NW)) % NW;
         float *d = dst + gi * per + cl0 * cplane;
         int soff = cl0 * csBytes;
-        for (int cl = cl0; cl < nch; cl += NW) {
-            if (o != kXSkip) {
+        if (o != kXSkip) {
+            for (int cl = cl0; cl < nch; cl += NW) {
                 if (vec)
                     bdma16(r, o, soff, d);
                 else
                     bdma4(r, o, soff, d);
+                soff += NW * csBytes;
+                d += NW * cplane;
             }
-            soff += NW * csBytes;
-            d += NW * cplane;
         }
     }
 }
@@ -498,9 +494,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
                                     cke - n1, xtab2, a.nG2, a.vec2, a.cplane, lw, lane);
             }
             const rsrc_t wr = make_rsrc(wsrc);
-            const int wv = lane * 16;
+            const int wv = lane * 16, room = total4 - lane;   // lanes past the slab must not write (next stage)
             for (int gi = lw; gi * 64 < total4; gi += 4)
-                if (gi * 64 + lane < total4) bdma16(wr, wv, gi * 1024, w_lds + gi * 256);
+                if (gi * 64 < room) bdma16(wr, wv, gi * 1024, w_lds + gi * 256);
         } else {
             const TileSrc src{a.x, a.x2, a.zeros, a.N, a.C1, a.C2, a.Hin, a.Win, a.up1, a.H1, a.W1, a.vec1, a.vec2};
             stage_input_dma(in_lds, src, pg, n0, iy0, ix0, c0, cke, lw, lane);
