@@ -14,6 +14,9 @@ SHAPES = {
     "head 384->384 1x1@64": (32, 384, 0, 64, 64, 0, 384, 1, (0, 0, 0, 0)),
     "head 384->96 1x1@64": (32, 384, 0, 64, 64, 0, 96, 1, (0, 0, 0, 0)),
     "dec3.0 up96+48->96@16": (128, 96, 48, 16, 16, 1, 96, 3, (2, 0, 1, 1)),
+    "net dec1.0 96+1->96@64": (128, 96, 1, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
+    "net dec2.0 96+48->96@32": (128, 96, 48, 32, 32, 0, 96, 3, (2, 0, 1, 1)),
+    "net dec3.0 96+48->96@16": (128, 96, 48, 16, 16, 0, 96, 3, (2, 0, 1, 1)),
     "det32->32@29 valid": (32, 32, 0, 29, 29, 0, 32, 3, (0, 0, 0, 0)),
     "det64->64@9 valid": (32, 64, 0, 9, 9, 0, 64, 3, (0, 0, 0, 0)),
     "enc48->48@4": (256, 48, 0, 4, 4, 0, 48, 3, (2, 0, 1, 1)),

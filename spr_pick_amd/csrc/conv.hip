@@ -612,6 +612,7 @@ struct WgArgs {
     int inRows, inCols, pitch, cplane, colOff;
     int xrow, g4, vec1, vec2, deal;
     int xtab;                // buffer-load staging of the row tiles (G, and x for 1x1)
+    int nG1, nG2;            // MODE 2: 256-float groups per staged x plane (source 1 / 2): table staging
     float invImg, invPitch;
 };
 
@@ -720,11 +721,12 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
     constexpr int kWgThreads = 256 * WJ;
     constexpr int kWgWaves = 4 * WJ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // LDS: ioff[ioffN] | pixoff[64] | rowd[16] | 2 x { x, g }
+    // LDS: ioff[ioffN] | pixoff[64] | rowd[16] | xp[(nG1+nG2)*64] xv[(nG1+nG2)*64] (MODE 2) | 2 x { x, g }
     int *ioff = reinterpret_cast<int *>(smem);
     int *pixoff = ioff + a.ioffN;
     int *rowd = pixoff + 64;
-    float *stage_base = smem + a.ioffN + 64 + 16;
+    int *xp = rowd + 16, *xv = xp + (a.nG1 + a.nG2) * 64;
+    float *stage_base = smem + a.ioffN + 64 + 16 + 2 * (a.nG1 + a.nG2) * 64;
     const int stageFloats = a.CKW * a.cplane + NT * 16 * 64;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -761,6 +763,23 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         if (c == 0) rowd[tid >> a.lgTC] = (off - tid) * 4;
     }
     const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal, kWgWaves};
+    if (MODE == 2) {
+        // x planes by buffer loads: per lane and 256-float group of a plane, the packed in-tile coordinates
+        // (-1: past the plane) and the byte offset against the tile origin; sources 1 and 2 back to back
+        const int imgElems = a.inRows * a.pitch, planeElems = NI * imgElems;
+        for (int idx = tid; idx < (a.nG1 + a.nG2) * 64; idx += kWgThreads) {
+            const int second = idx >= a.nG1 * 64;
+            const int gi = (idx - (second ? a.nG1 * 64 : 0)) >> 6, ln = idx & 63;
+            const int e = gi * 256 + ln * 4;
+            const int il = fast_div(e, a.invImg);
+            const int rem = e - il * imgElems;
+            const int r = fast_div(rem, a.invPitch);
+            const int j = rem - r * a.pitch;
+            const long imgStride = second ? (long)a.C2 * planeI : (long)a.C1 * planeI;
+            xp[idx] = e < planeElems ? (il << 20) | (r << 10) | j : -1;
+            xv[idx] = (int)((il * imgStride + (long)r * a.Win + j) * 4);
+        }
+    }
     // G rows (and, for 1x1, x rows): lane -> (row within the item's 4 rows, swizzled 16-byte chunk) -> pixel
     const int rowl = lane >> 4;
     int gpk, gvo, xvo;
@@ -819,7 +838,38 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         if (XROW) {
             stage_rows_buf(x_lds, a.x, a.C1, planeI, a.Win, c0, cke, Cin, n0, oy0, ox0, xvo, inside);
         } else {
-            stage_input_dma(x_lds, src, pg, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, c0, cke, lw, lane);
+            if (MODE == 2) {
+                // table + buffer-load staging: one validity pass per 256-float group and tile, then a
+                // wave-uniform channel offset per DMA; lanes outside the image read zeros by range check
+                const int iy0 = oy0 - a.padT, ixa = ox0 - a.padL - a.colOff;
+                const int n1 = max(0, min(c0 + cke, a.C1) - c0);   // channels of this chunk taken from x
+                auto planes = [&](const float *base, int nch, int nG, int tb, float *dstp) {
+                    const rsrc_t r = make_rsrc(base + (long)iy0 * a.Win + ixa);
+                    for (int gi = 0; gi < nG; ++gi) {
+                        const int pk = xp[tb + gi * 64 + lane], vo = xv[tb + gi * 64 + lane];
+                        const int rr = (pk >> 10) & 1023, jj = pk & 1023, il = pk >> 20;
+                        const bool ok = n0 + il < a.N && (unsigned)(iy0 + rr) < (unsigned)a.Hin &&
+                                        (unsigned)(ixa + jj) < (unsigned)a.Win;
+                        const int o = ok ? vo : kXZero;
+                        const int cl0 = (lw + kWgWaves - (gi % kWgWaves)) % kWgWaves;
+                        float *d = dstp + gi * 256 + cl0 * a.cplane;
+                        int soff = cl0 * (int)planeI * 4;
+                        if (pk >= 0) {
+                            for (int cl = cl0; cl < nch; cl += kWgWaves) {
+                                bdma16(r, o, soff, d);
+                                soff += kWgWaves * (int)planeI * 4;
+                                d += kWgWaves * a.cplane;
+                            }
+                        }
+                    }
+                };
+                if (n1 > 0) planes(a.x + ((long)n0 * a.C1 + c0) * planeI, n1, a.nG1, 0, x_lds);
+                if (n1 < cke)
+                    planes(a.x2 + ((long)n0 * a.C2 + (max(c0, a.C1) - a.C1)) * planeI, cke - n1, a.nG2, a.nG1 * 64,
+                           x_lds + n1 * a.cplane);
+            } else {
+                stage_input_dma(x_lds, src, pg, n0, oy0 * a.stride - a.padT, ox0 * a.stride - a.padL, c0, cke, lw, lane);
+            }
         }
         if (FAST) {
             stage_rows_buf(g_lds, a.gy, a.Cout, planeO, a.Wout, co0, NT * 16, a.Cout, n0, oy0, ox0, gvo, inside);
@@ -1396,7 +1446,7 @@ struct WgPlan {
     int IT, NT, lgTC, lgTR, tilesX, tilesY, nTiles, tilesPerGroup, groups;
     int CKW, nChunks, nblkN, ioffN, CoutP;
     int inRows, inCols, pitch, cplane, colOff, xrow;
-    int mode;
+    int mode, nG1, nG2;
     size_t ldsBytes, wsBytes;
 };
 
@@ -1440,10 +1490,17 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     // the G tile again); equal-sized chunks so every workgroup carries the same load.
     constexpr int kMaxIT = 7;
     // operand addressing of the tile loop: 1 = 1x1 rows, 2 = stride-1 tiles with rows of >= 4 pixels, 0 = any
-    p->mode = p->xrow ? 1 : (g->stride == 1 && TC >= 4) ? 2 : 0;
+    // (MODE 2 also stages the x planes through offset tables and 16-byte buffer loads: aligned rows, no upsampling)
+    p->mode = p->xrow ? 1 : (g->stride == 1 && TC >= 4 && vecGeo && !g->up1) ? 2 : 0;
+    {
+        const int planeElems = NI * p->inRows * p->pitch;
+        p->nG1 = p->mode == 2 ? sprk::cdiv(planeElems, 256) : 0;
+        p->nG2 = (p->mode == 2 && g->C2 > 0) ? sprk::cdiv(planeElems, 256) : 0;
+        if (p->inRows >= 1024 || p->pitch >= 1024) p->mode = p->xrow ? 1 : 0, p->nG1 = p->nG2 = 0;
+    }
     auto lds = [&](int ck) {
         const int ioffN = sprk::roundup(sprk::roundup(ck * KHW, 16), 4);
-        return (size_t)(ioffN + 64 + 16 + 2 * (ck * p->cplane + NT * 16 * 64)) * 4;
+        return (size_t)(ioffN + 64 + 16 + 2 * (p->nG1 + p->nG2) * 64 + 2 * (ck * p->cplane + NT * 16 * 64)) * 4;
     };
     int CKW = 0, bestCost = 1 << 30;
     for (int nCh = 1; nCh <= Cin; ++nCh) {
@@ -1691,7 +1748,11 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
         sprk::set_error("conv2d_bwd_weight: 1x1 row staging needs 16-byte aligned x / gy and < 2^28-element tiles");
         return SPRK_EINVAL;
     }
-    const int mode = fast ? p.mode : 0;
+    // MODE 2 additionally needs 16-byte aligned x / x2 (the general kernel ignores the table area in LDS)
+    const bool planesOk = a.vec1 && (g->C2 == 0 || a.vec2);
+    const int mode = !fast ? 0 : (p.mode == 2 && !planesOk) ? 0 : p.mode;
+    a.nG1 = p.nG1;
+    a.nG2 = p.nG2;
     dim3 grid(p.groups, p.nChunks, p.nblkN);
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * g->KH * g->KW;
     sprk::prof_begin(1, flops, s);
