@@ -189,12 +189,14 @@ int sprk_nms2d(const float *scores, int H, int W, int r, float threshold,
                int rounds, int resume, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- in-library kernel timing (bench.py's roofline leg) --------------------------------
- * When enabled, every launch of the MFMA convolution kernels is bracketed by HIP events
- * on its own stream; sprk_prof_collect synchronises those events and returns, per kernel
- * class (0 = conv_mfma_kernel<4, 6>, the dominant forward / backward-data instantiation;
- * 1 = conv_wgrad_mfma_kernel (all instantiations); 2 = the other conv_mfma_kernel
- * instantiations), the launch count, the summed duration in ms and the summed algorithmic FLOPs. */
-void sprk_prof_enable(int on);
+ * sprk_prof_enable(mask): bit k set = every launch of kernel class k is bracketed by HIP events
+ * on its own stream (an event pair costs the GPU front end a few microseconds, so the timed
+ * region of bench.py enables class 0 only); sprk_prof_collect synchronises those events and
+ * returns, per kernel class (0 = conv_mfma_kernel<4, 6, *>, the dominant forward /
+ * backward-data tile shape; 1 = conv_wgrad_mfma_kernel (all instantiations); 2 = the other
+ * conv_mfma_kernel instantiations), the launch count, the summed duration in ms and the
+ * summed algorithmic FLOPs. */
+void sprk_prof_enable(int mask);
 int sprk_prof_collect(int kclass, long *launches, double *ms, double *flops);
 
 #ifdef __cplusplus

@@ -25,13 +25,13 @@ struct ProfRec {
     double flops;
 };
 static std::mutex g_prof_mu;
-static bool g_prof_on = false;
+static int g_prof_mask = 0;   // bit k: kernel class k is bracketed by events
 static std::vector<ProfRec> g_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
 static thread_local int t_open = -1;
 
 void prof_begin(int kclass, double flops, hipStream_t s) {
-    if (!g_prof_on) return;
+    if (!((g_prof_mask >> kclass) & 1)) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
     if (!g_pool.empty()) {
@@ -49,8 +49,7 @@ void prof_begin(int kclass, double flops, hipStream_t s) {
 }
 
 void prof_end(int kclass, hipStream_t s) {
-    (void)kclass;
-    if (!g_prof_on || t_open < 0) return;
+    if (!((g_prof_mask >> kclass) & 1) || t_open < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (t_open < (int)g_recs.size()) (void)hipEventRecord(g_recs[t_open].b, s);
     t_open = -1;
@@ -67,7 +66,7 @@ void sprk_set_naive(int on) { sprk::g_naive = on ? 1 : 0; }
 
 void sprk_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(sprk::g_prof_mu);
-    sprk::g_prof_on = on != 0;
+    sprk::g_prof_mask = on;
 }
 
 int sprk_prof_collect(int kclass, long *launches, double *ms, double *flops) {
