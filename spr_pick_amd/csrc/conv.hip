@@ -703,9 +703,9 @@ __device__ __forceinline__ void wgrad_tile(f32x4 (&acc)[IT][NT], int xaddr, cons
     }
 }
 
-// (Measured and dropped for this kernel: staging the x planes through per-tile offset tables and buffer
-// loads as conv_mfma_kernel does — here the tile moves every 64 pixels, the per-tile validity pass costs more
-// VALU than the pointer arithmetic it replaces.  The row tiles (G, and x for 1x1) do use buffer loads.)
+// (A first version of MODE 2's table staging of the x planes kept the per-group offsets in a small register
+// array and was slower than pointer arithmetic: the array cost more VALU — initialisation, guarded reads,
+// indexed access — than it saved.  Written as plain loops that read each table entry where it is used, it wins.)
 
 // WJ = 2: eight waves (two per SIMD); wave (wi, wj) owns k-tiles wi, wi+4, ... x the wj-th half of the
 // NT cout tiles, so that one wave's LDS latency and barrier skew are covered by its SIMD partner.
