@@ -293,12 +293,13 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.groups = 1   # > 1: the batch holds that many stacked passes (JointNetwork.forward_pair)
 
     def forward(self, x, relu=False):
         if self.training:
-            self.num_batches_tracked += 1
+            self.num_batches_tracked += self.groups
             return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var,
-                                        self.momentum, self.eps, relu)
+                                        self.momentum, self.eps, relu, groups=self.groups)
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             scale, shift = self.folded()
             y = x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
@@ -548,13 +549,25 @@ class JointNetwork(nn.Module):
 
     def forward_pair(self, x, x2, eps=None, eps2=None):
         """Two forward passes (the training step's original and flipped batch, denoiser_v2.py:295-311)
-        with the stateless blind-spot U-Net evaluated once on the concatenated batch — twice the work
-        per kernel launch, identical results.  The detector (BatchNorm: batch statistics and running
-        averages per pass) still runs once per pass, in the reference's order."""
+        as ONE pass over the stacked batch — twice the work per kernel launch, half the launches.  The
+        blind-spot U-Net is stateless.  The detector's BatchNorm layers are told that the batch holds two
+        passes: each half gets its own batch statistics and the running averages are updated half after
+        half, which is what two separate calls do (no BatchNorm output depends on another layer's running
+        average, so the final buffers are the same)."""
         B = x.shape[0]
         res = self.denoise_branch(torch.cat((x, x2), dim=0))
         both = res[0] if isinstance(res, tuple) else res
         out1, out2 = both[:B], both[B:]
-        det1 = self.detector(self.reparameterize(out1, eps))
-        det2 = self.detector(self.reparameterize(out2, eps2))
-        return (out1, det1), (out2, det2)
+        if not self.training:
+            return (out1, self.detector(self.reparameterize(out1, eps))), \
+                   (out2, self.detector(self.reparameterize(out2, eps2)))
+        z = torch.cat((self.reparameterize(out1, eps), self.reparameterize(out2, eps2)), dim=0)
+        bns = [m for m in self.detector.modules() if isinstance(m, BatchNorm2d)]
+        for m in bns:
+            m.groups = 2
+        try:
+            det = self.detector(z)
+        finally:
+            for m in bns:
+                m.groups = 1
+        return (out1, det[:B]), (out2, det[B:])

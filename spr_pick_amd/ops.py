@@ -232,21 +232,31 @@ def unrot4_shift_concat(d):
 
 # ---- BatchNorm ------------------------------------------------------------------------------------
 class _BNTrainFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d (+ ReLU).  ``groups`` > 1: the batch is `groups` independent passes stacked
+    along N — every group gets its own batch statistics and the running averages are updated group after
+    group, exactly as if the module had been called once per pass (the convolutions around it can then run
+    once on the stacked batch)."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, groups):
         x = x.contiguous()
         _need_gpu(x, gamma, beta)
         N, C, H, W = x.shape
+        if N % groups:
+            raise ValueError("batch_norm_train: batch %d is not divisible into %d groups" % (N, groups))
+        Ng = N // groups
         y = torch.empty_like(x)
-        mean = torch.empty(C, dtype=torch.float32, device=x.device)
-        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        mean = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+        invstd = torch.empty((groups, C), dtype=torch.float32, device=x.device)
         L = _lib.lib()
-        nb = L.sprk_bn_ws_bytes(N, C, H * W)
+        nb = L.sprk_bn_ws_bytes(Ng, C, H * W)
         ws = _ws(nb, x)
-        check(L.sprk_bn_train_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                  _p(mean), _p(invstd), N, C, H * W, momentum, eps, int(relu), _p(ws), nb, _stream()),
-              "sprk_bn_train_fwd")
-        ctx.relu = relu
+        for g in range(groups):
+            sl = slice(g * Ng, (g + 1) * Ng)
+            check(L.sprk_bn_train_fwd(_p(x[sl]), _p(y[sl]), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                      _p(mean[g]), _p(invstd[g]), Ng, C, H * W, momentum, eps, int(relu), _p(ws), nb,
+                                      _stream()), "sprk_bn_train_fwd")
+        ctx.relu, ctx.groups = relu, groups
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         return y
 
@@ -255,19 +265,29 @@ class _BNTrainFn(torch.autograd.Function):
         x, y, gamma, mean, invstd = ctx.saved_tensors
         gy = gy.contiguous()
         N, C, H, W = x.shape
+        groups = ctx.groups
+        Ng = N // groups
         gx = torch.empty_like(x)
-        gg = torch.empty(C, dtype=torch.float32, device=x.device)
-        gb = torch.empty(C, dtype=torch.float32, device=x.device)
+        gg = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+        gb = torch.empty((groups, C), dtype=torch.float32, device=x.device)
         L = _lib.lib()
-        nb = L.sprk_bn_ws_bytes(N, C, H * W)
+        nb = L.sprk_bn_ws_bytes(Ng, C, H * W)
         ws = _ws(nb, x)
-        check(L.sprk_bn_train_bwd(_p(gy), _p(x), _p(y), _p(gamma), _p(mean), _p(invstd), _p(gx), _p(gg), _p(gb),
-                                  N, C, H * W, int(ctx.relu), _p(ws), nb, _stream()), "sprk_bn_train_bwd")
-        return gx, gg, gb, None, None, None, None, None
+        for g in range(groups):
+            sl = slice(g * Ng, (g + 1) * Ng)
+            check(L.sprk_bn_train_bwd(_p(gy[sl]), _p(x[sl]), _p(y[sl]), _p(gamma), _p(mean[g]), _p(invstd[g]),
+                                      _p(gx[sl]), _p(gg[g]), _p(gb[g]), Ng, C, H * W, int(ctx.relu), _p(ws), nb,
+                                      _stream()), "sprk_bn_train_bwd")
+        if groups > 1:
+            gg, gb = gg.sum(0), gb.sum(0)
+        else:
+            gg, gb = gg[0], gb[0]
+        return gx, gg, gb, None, None, None, None, None, None
 
 
-def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=False):
-    return _BNTrainFn.apply(x, gamma, beta, running_mean, running_var, float(momentum), float(eps), bool(relu))
+def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=False, groups=1):
+    return _BNTrainFn.apply(x, gamma, beta, running_mean, running_var, float(momentum), float(eps), bool(relu),
+                            int(groups))
 
 
 def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, relu=False):
