@@ -909,19 +909,32 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
     const int gaddr0 = lds_addr(stage_base + a.CKW * a.cplane + wj * (NTW * 16 * 64) + l15 * 64);
     const lds_cip pixoffp = lds_i(lds_addr(pixoff)), rowdp = lds_i(lds_addr(rowd));
 
-    int bsel = 0;
-    for (int tile = t_begin; tile < t_end; ++tile, bsel ^= 1) {
-        __syncthreads();  // this tile landed everywhere; previous tile fully consumed
-        if (tile + 1 < t_end) issue(tile + 1, bsel ^ 1);
-        const int soff = bsel * stageFloats * 4;
-        const int xaddr = xaddr0 + soff, gaddr = gaddr0 + soff;
-        if (myIT >= IT) {
+    // The tile loop is written once per k-tile count of this wave (a wave-uniform choice made once): with the
+    // choice inside the loop the three variants get different accumulator registers and the compiler copies
+    // all 84 of them at every join — 36-72 v_mov per tile, each costing MFMA issue time.
+    auto tiles = [&](auto body) {
+        int bsel = 0;
+        for (int tile = t_begin; tile < t_end; ++tile, bsel ^= 1) {
+            __syncthreads();  // this tile landed everywhere; previous tile fully consumed
+            if (tile + 1 < t_end) issue(tile + 1, bsel ^ 1);
+            const int soff = bsel * stageFloats * 4;
+            body(xaddr0 + soff, gaddr0 + soff);
+        }
+    };
+    if (myIT >= IT) {
+        tiles([&](int xaddr, int gaddr) {
             wgrad_tile<IT, IT, NTW, MODE, WJ == 1>(acc, xaddr, ioffb, gaddr, pixoffp, rowdp, a.lgTC, gsw, lq);
-        } else if (IT > 1 && myIT == IT - 1) {
+        });
+    } else if (IT > 1 && myIT == IT - 1) {
+        tiles([&](int xaddr, int gaddr) {
             wgrad_tile<(IT > 1 ? IT - 1 : 1), IT, NTW, MODE, WJ == 1>(acc, xaddr, ioffb, gaddr, pixoffp, rowdp, a.lgTC, gsw,
                                                                       lq);
-        } else if (myIT > 0) {
-            // short tail chunk: predicate per k-tile (rare: last channel chunk of a layer); same pixel order
+        });
+    } else {
+        // short tail chunk: predicate per k-tile (rare: last channel chunk of a layer); same pixel order.
+        // (waves without k-tiles still take part in the staging and the barriers)
+        tiles([&](int xaddr, int gaddr) {
+            if (myIT <= 0) return;
 #pragma unroll 1
             for (int ks = 0; ks < 16; ++ks) {
                 const int j = ks >> 2, sx = ks & 3;
@@ -941,7 +954,7 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
                     }
                 }
             }
-        }
+        });
     }
     // partial slab of this group: rows = global k (c*KHW + tap), cols = cout (64-byte runs per store)
     float *dst = a.partial + (long)blockIdx.x * Cin * KHW * a.CoutP;
