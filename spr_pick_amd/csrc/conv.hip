@@ -1471,7 +1471,7 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     p->nblkN = sprk::cdiv(ntile, NT);
     p->CoutP = p->nblkN * NT * 16;
     const int TM = 64;
-    int TC = std::min(sprk::pow2_ceil(g->Wout), dbg_int("SPRK_WG_TC", 64));
+    int TC = std::min(sprk::pow2_ceil(g->Wout), 64);
     if (g->dil * (g->KW - 1) >= 8) TC = std::min(TC, 8);
     int TR = std::min(TM / TC, sprk::pow2_ceil(g->Hout));
     int NI = TM / (TC * TR);
@@ -1537,7 +1537,8 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     // one workgroup per CU (the stages fill most of the LDS): never more workgroups than CUs, or the
     // surplus runs as a second, nearly empty round
     const int per = p->nChunks * p->nblkN;
-    int groups = std::max(1, std::min(p->nTiles, dbg_int("SPRK_WG_BLOCKS", 256) / per));
+    static const int kWgBlocks = dbg_int("SPRK_WG_BLOCKS", 256);   // debug knob (sweeps); 256 = one per CU
+    int groups = std::max(1, std::min(p->nTiles, kWgBlocks / per));
     p->tilesPerGroup = sprk::cdiv(p->nTiles, groups);
     p->groups = sprk::cdiv(p->nTiles, p->tilesPerGroup);
     p->wsBytes = ((size_t)kZeroFloats + (size_t)p->groups * Cin * KHW * p->CoutP) * sizeof(float);
