@@ -21,6 +21,11 @@ from .datasets import DetectionDataset
 PAD_MULTIPLE = 32     # JointNetwork.input_wh_mul()
 
 
+def load_reference_images(gt_path):
+    """{name: array} of the clean reference micrographs (same table / directory formats as the inputs)."""
+    return {name: micrograph_io.load_image(path) for _, name, path in micrograph_io.read_image_table(gt_path)}
+
+
 def load_micrographs(image_path, label_path=None, radius=3, bb=24):
     """-> (groups, names): groups[g][i] = (image array, mask uint8, hm float32); the grouping and
     order of MicrographDataset.load_data / match_images_targets (micrograph.py:166-292)."""
@@ -134,8 +139,11 @@ def pad_to_network_size(t):
 class MicrographFeed:
     """Whole micrographs for evaluation, one per batch, in dataset order (wrapping to `count`)."""
 
-    def __init__(self, groups, names, count=None, device="cuda", rank=0, world=1):
+    def __init__(self, groups, names, count=None, device="cuda", rank=0, world=1, gt=None):
+        """gt: optional {name: clean reference image array} (the reference's --validation_gt / --gt_dataset):
+        carried in the metadata for the evaluator's PSNR figures."""
         self.device = torch.device(device)
+        self.gt = gt or {}
         self.items = list(zip(groups[0], names[0])) if groups else []
         if not self.items:
             raise ValueError("empty evaluation set")
@@ -155,5 +163,8 @@ class MicrographFeed:
                   DetectionDataset.Metadata.NAME: [name],
                   DetectionDataset.Metadata.IMAGE_SHAPE: torch.tensor([list(shape)]),
                   DetectionDataset.Metadata.GT: []}
+            if name in self.gt:   # to_tensor + permute of the clean image, un-padded (train.py:788-809)
+                g = micrograph_io.to_unit_float(self.gt[name]).T[None]
+                md[DetectionDataset.Metadata.GT] = [torch.from_numpy(np.ascontiguousarray(g))]
             hm_t = torch.from_numpy(np.ascontiguousarray(pad_to_network_size(hm.T[None])))[None]
             yield pos, DetectionDataset.make_batch(inp, hm_t[..., :shape[1], :shape[2]], hm=hm_t, metadata=md)

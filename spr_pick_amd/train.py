@@ -217,9 +217,34 @@ class DenoiserTrainer:
                 image_count = data[DetectionDataset.INPUT].shape[0]
                 outputs = self.denoiser.run_pipeline(data, train=False)
                 eval_history["n"] += image_count
+                clean = outputs[PipelineOutput.INPUTS][DetectionDataset.METADATA][DetectionDataset.Metadata.GT]
+                if len(clean) > 0:   # PSNR against the clean reference images (train.py:404-413)
+                    for key, name in self.img_outputs(prefix="psnr").items():
+                        eval_history[name] += self.calculate_psnr(outputs, key)
                 if output_callback:
                     output_callback(idx, outputs)
         self.denoiser.unfill()
+
+    def img_outputs(self, prefix=None):
+        """Image outputs of the configured pipeline -> metric names (train.py:763-779)."""
+        outputs = {PipelineOutput.IMG_DENOISED: "out"}
+        if self.cfg[ConfigValue.PIPELINE] == Pipeline.SSDN:
+            outputs[PipelineOutput.IMG_MU] = "mu_out"
+        return {k: "_".join((prefix, v)) if prefix else v for k, v in outputs.items()}
+
+    @staticmethod
+    def calculate_psnr(outputs, key):
+        """Per image: 20 log10(1) - 10 log10(mean squared error) between the un-padded output and the clean
+        reference (train.py:781-814, utils/data.py:124-135) -> tensor [B]."""
+        metadata = outputs[PipelineOutput.INPUTS][DetectionDataset.METADATA]
+        clean = metadata[DetectionDataset.Metadata.GT]
+        shapes = metadata[DetectionDataset.Metadata.IMAGE_SHAPE]
+        vals = []
+        for img, ref, shape in zip(outputs[key], clean, shapes):
+            c, h, w = (int(v) for v in shape)
+            mse = torch.mean((img[:c, :h, :w] - ref.to(img.device)) ** 2)
+            vals.append(-10.0 * torch.log10(mse))
+        return torch.stack(vals)
 
     def validation_output_callback(self, output_index):
         def callback(output_0_index, outputs):
@@ -430,8 +455,7 @@ class DenoiserTrainer:
     def train_data(self):
         c = self.cfg
         self._require_txt(ConfigValue.TRAIN_DATASET_TYPE)
-        if c.get(ConfigValue.TRAIN_GT_PATH):
-            logger.warning("--train_gt is ignored: ground-truth PSNR tracking is not built")
+        # (--train_gt is loaded by the reference's dataset but never read by its training loop: ignored here)
         groups, names = feed_mod.load_micrographs(c[ConfigValue.TRAIN_DATA_PATH], c[ConfigValue.TRAIN_LABEL_PATH],
                                                   radius=3, bb=c[ConfigValue.BB])
         batch = c[ConfigValue.TRAIN_MINIBATCH_SIZE]
@@ -444,12 +468,11 @@ class DenoiserTrainer:
     def test_data(self):
         c = self.cfg
         self._require_txt(ConfigValue.TEST_DATASET_TYPE)
-        if c.get(ConfigValue.TEST_GT_PATH):
-            logger.warning("ground-truth images are ignored: PSNR tracking is not built")
+        gt = feed_mod.load_reference_images(c[ConfigValue.TEST_GT_PATH]) if c.get(ConfigValue.TEST_GT_PATH) else None
         groups, names = feed_mod.load_micrographs(c[ConfigValue.TEST_DATA_PATH], c.get(ConfigValue.TEST_LABEL_PATH),
                                                   radius=3, bb=c[ConfigValue.BB])
         return feed_mod.MicrographFeed(groups, names, count=cfg_mod.test_length(c), device=self.device,
-                                       rank=self.rank, world=self.world)
+                                       rank=self.rank, world=self.world, gt=gt)
 
     def set_train_data(self, path):
         self.cfg[ConfigValue.TRAIN_DATA_PATH] = path

@@ -209,3 +209,31 @@ def test_two_rank_training_and_sharded_eval(tmp_path):
     assert len(ev) == 1
     files = os.listdir(os.path.join(runs, ev[0], "eval_imgs"))
     assert "mic0_scores.txt" in files and "mic1_scores.txt" in files
+
+
+def test_eval_reports_psnr_against_reference_images(tmp_path):
+    """`joint eval --gt_dataset`: psnr_out / psnr_mu_out = -10 log10(mean squared error) of the un-padded
+    outputs against the clean images (train.py:404-413, :781-814)."""
+    from spr_pick_amd import cli, micrograph_io
+    from spr_pick_amd.params import HistoryValue, StateValue
+    imgs, lab = _write_set(str(tmp_path), n=1)
+    runs = str(tmp_path / "runs")
+    t = cli.start(("train start -a ssdn -n gaussian --noise_value var -t %s -l %s -ap 0.75 -tau 0.01 -iter 16 "
+                   "--train_batch_size 16 --print_interval 16 --checkpoint_interval 16 --runs_dir %s"
+                   % (imgs, lab, runs)).split())
+    # the "clean" set: the same micrograph (any image of the right size would do)
+    gt_dir = tmp_path / "gt"
+    gt_dir.mkdir()
+    src = micrograph_io.load_image(os.path.join(str(tmp_path), "mic0.mrc"))
+    with open(gt_dir / "mic0.mrc", "wb") as f:
+        micrograph_io.write_mrc(f, src.astype(np.float32))
+    ev = cli.start(["eval", "-m", os.path.join(t.run_dir_path, "final-ssdn-gaussian.wt"), "-d", imgs, "-g", str(gt_dir),
+                    "--runs_dir", runs, "--num", "1"])
+    h = ev.state[StateValue.HISTORY][HistoryValue.EVAL]
+    assert h["n"] == 1 and not h["psnr_out"].empty() and not h["psnr_mu_out"].empty()
+    psnr = float(h["psnr_out"].accumulated())
+    from PIL import Image
+    out = np.array(Image.open(os.path.join(ev.run_dir_path, "eval_imgs", "mic0_out.png")))
+    assert out.shape == (320, 320) and np.isfinite(psnr) and 0.0 < psnr < 80.0
+    log = open(os.path.join(ev.run_dir_path, "log.txt")).read()
+    assert "psnr_out=" in log and "psnr_mu_out=" in log
