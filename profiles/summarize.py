@@ -60,6 +60,28 @@ with open(os.path.join(here, tag + "_bench_kernel_stats.csv"), "w", newline="") 
         w.writerow([k, c, t, "%.1f" % (t / c), "%.3f" % (100.0 * t / total), "", ""])
 
 
+def kernel_csv(sub, name, note):
+    rows = list(db(sub).execute("select name, count(*), sum(end-start), avg(end-start) from kernels group by name "
+                                "order by 3 desc"))
+    total = sum(r[2] for r in rows)
+    fam = collections.OrderedDict()
+    for n, c, t, a in rows:
+        e = fam.setdefault(family(short(n)), [0, 0])
+        e[0] += c
+        e[1] += t
+    with open(os.path.join(here, name), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["# " + note])
+        w.writerow(["Family", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+        for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, c, t, "%.1f" % (t / c), "%.3f" % (100.0 * t / total)])
+
+
+if os.path.isdir(os.path.join(src, "infer")):
+    kernel_csv("infer", tag + "_infer4096_kernel_stats.csv",
+               "scratch/infer_prof.py 4096: three filled 4096x4096 inferences + NMS (first one includes warm-up)")
+
+
 def counters(sub):
     out = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     for k, cn, v in db(sub).execute("select kernel_name, counter_name, value from counters_collection"):
