@@ -21,6 +21,9 @@ SHAPES = {
     "det64->64@9 valid": (32, 64, 0, 9, 9, 0, 64, 3, (0, 0, 0, 0)),
     "enc48->48@4": (256, 48, 0, 4, 4, 0, 48, 3, (2, 0, 1, 1)),
     "enc48->48@8": (256, 48, 0, 8, 8, 0, 48, 3, (2, 0, 1, 1)),
+    "inf48->48@1024": (4, 48, 0, 1024, 1024, 0, 48, 3, (2, 0, 1, 1)),
+    "inf48->48@512": (4, 48, 0, 512, 512, 0, 48, 3, (2, 0, 1, 1)),
+    "enc48->48@32": (128, 48, 0, 32, 32, 0, 48, 3, (2, 0, 1, 1)),
     "cin4->96@64": (128, 4, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
     "cin8->96@64": (128, 8, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
     "cin16->96@64": (128, 16, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
