@@ -69,6 +69,8 @@ const char *sprk_last_error(void);
 int sprk_version(void);
 /* number of HIP kernel launches issued by this library since load (diagnostics) */
 long sprk_launch_count(void);
+/* number of convolutions (forward or backward-data) that took the Winograd F(2x2,3x3) kernel (diagnostics) */
+long sprk_wino_launch_count(void);
 /* debug switch: 1 = route convolutions through the direct (non-MFMA) kernels */
 void sprk_set_naive(int on);
 

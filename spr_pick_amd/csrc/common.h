@@ -11,7 +11,7 @@
 namespace sprk {
 
 void set_error(const char *fmt, ...);
-extern std::atomic<long> g_launches;
+extern std::atomic<long> g_launches, g_wino_launches;
 extern int g_naive;
 
 // event bracketing of the MFMA convolution launches (sprk_prof_*)

@@ -17,6 +17,7 @@
 // maths: they serve strided backward-data (tiny detector layers) and as an on-device
 // cross-check (sprk_set_naive).
 #include "common.h"
+#include "wino.h"
 
 #include <cstdlib>
 
@@ -1583,6 +1584,23 @@ int launch_wg(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
     return SPRK_EINVAL;
 }
 
+// Winograd path (wino.hip): geometry of the forward layer / of its backward-data correlation
+sprk::WinoGeom wino_geom_fwd(const sprk_conv_geom *g, const sprk_conv_epilogue *ep) {
+    return sprk::WinoGeom{g->N, g->C1, g->C2, g->Cout, g->Hin, g->Win, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil,
+                          g->pad_top, g->pad_left, g->up1, ep ? ep->up2 : 0, (ep && ep->res) ? 1 : 0};
+}
+sprk::WinoGeom wino_geom_bwd(const sprk_conv_geom *g) {
+    return sprk::WinoGeom{g->N, g->Cout, 0, g->C1 + g->C2, g->Hout, g->Wout, g->Hin, g->Win, g->KH, g->KW, g->stride, g->dil,
+                          (g->KH - 1) * g->dil - g->pad_top, (g->KW - 1) * g->dil - g->pad_left, g->up1, 0, 0};
+}
+size_t wino_ws_fwd(const sprk_conv_geom *g) {
+    return sprk::wino_eligible(wino_geom_fwd(g, nullptr)) ? sprk::wino_ws_bytes(g->C1, g->C2, g->Cout) : 0;
+}
+size_t wino_ws_bwd(const sprk_conv_geom *g) {
+    return sprk::wino_eligible(wino_geom_bwd(g)) ? sprk::wino_ws_bytes(g->Cout, 0, g->C1 + g->C2) : 0;
+}
+constexpr int kClassWino = 3;   // profiling class of the 96-channel Winograd kernel
+
 }  // namespace
 
 // ==========================================================================================
@@ -1595,7 +1613,7 @@ size_t sprk_conv2d_fwd_ws_bytes(const sprk_conv_geom *g) {
     FwdPlan p;
     if (!plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, g->pad_left, g->up1,
                   g->C2 > 0, g->Win, &p)) return 0;
-    return p.wsBytes;
+    return std::max(p.wsBytes, wino_ws_fwd(g));
 }
 
 int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, const sprk_conv_geom *g,
@@ -1612,6 +1630,20 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
         const long total = (long)g->N * g->Cout * g->Hout * g->Wout;
         hipLaunchKernelGGL(conv_fwd_direct_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, s, a);
         return sprk::check_launch("conv_fwd_direct");
+    }
+    if (sprk::wino_eligible(wino_geom_fwd(g, ep)) && !ep->up2 && !ep->res) {
+        const size_t need = sprk::wino_ws_bytes(g->C1, g->C2, g->Cout);
+        if (ws_bytes < need || !ws) {
+            sprk::set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
+            return SPRK_EWORKSPACE;
+        }
+        sprk::WinoArgs wa{x, x2, w, ep->bias, ep->scale, ep->shift, y, (float *)ws, g->N, g->C1, g->C2, g->Hin, g->Win,
+                          g->Cout, g->pad_top, g->pad_left, ep->act, 0};
+        const int kclass = g->Cout > 48 ? kClassWino : 2;
+        sprk::prof_begin(kclass, 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * 9, s);
+        if (int rc = sprk::wino_conv(wa, s)) return rc;
+        sprk::prof_end(kclass, s);
+        return sprk::check_launch("wino_conv");
     }
     FwdPlan p;
     SPRK_REQUIRE(plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, g->pad_left, g->up1,
@@ -1650,7 +1682,7 @@ size_t sprk_conv2d_bwd_data_ws_bytes(const sprk_conv_geom *g) {
     FwdPlan p;
     if (!plan_fwd(g->N, g->Cout, g->C1 + g->C2, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, (g->KW - 1) * g->dil - g->pad_left, 0, 0,
                   g->Wout, &p)) return 0;
-    return p.wsBytes;
+    return std::max(p.wsBytes, wino_ws_bwd(g));
 }
 
 int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk_conv_geom *g, void *ws,
@@ -1667,6 +1699,20 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
         return sprk::check_launch("conv_bwd_data_direct");
     }
     // gin = correlation of gy with the flipped, channel-transposed kernel
+    if (sprk::wino_eligible(wino_geom_bwd(g))) {
+        const size_t need = sprk::wino_ws_bytes(g->Cout, 0, Cin);
+        if (ws_bytes < need || !ws) {
+            sprk::set_error("conv2d_bwd_data: workspace %zu < %zu", ws_bytes, need);
+            return SPRK_EWORKSPACE;
+        }
+        sprk::WinoArgs wa{gy, nullptr, w, nullptr, nullptr, nullptr, gin, (float *)ws, g->N, g->Cout, 0, g->Hout, g->Wout,
+                          Cin, (g->KH - 1) * g->dil - g->pad_top, (g->KW - 1) * g->dil - g->pad_left, SPRK_ACT_NONE, 1};
+        const int kclass = Cin > 48 ? kClassWino : 2;
+        sprk::prof_begin(kclass, 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * 9, s);
+        if (int rc = sprk::wino_conv(wa, s)) return rc;
+        sprk::prof_end(kclass, s);
+        return sprk::check_launch("wino_conv(bwd_data)");
+    }
     FwdPlan p;
     SPRK_REQUIRE(plan_fwd(g->N, g->Cout, Cin, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, (g->KW - 1) * g->dil - g->pad_left, 0, 0,
                           g->Wout, &p),

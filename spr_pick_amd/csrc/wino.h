@@ -1,0 +1,24 @@
+// Winograd F(2x2, 3x3) path of the 3x3 stride-1 convolutions (wino.hip); called from conv.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sprk {
+
+struct WinoGeom {
+    int N, C1, C2, Cout, H, W, Hout, Wout, KH, KW, stride, dil, padT, padL, up1, up2, res;
+};
+struct WinoArgs {
+    const float *x, *x2;   // sources [N,C1,H,W], [N,C2,H,W] (x2 may be null)
+    const float *w;        // taps in the layout of the forward layer, [CoutF][CinF][3][3]
+    const float *bias, *scale, *shift;
+    float *y;              // [N,Cout,H,W]
+    float *U;              // workspace of wino_ws_bytes()
+    int N, C1, C2, H, W, Cout, padT, padL, act;
+    int mode;              // 0: forward taps w[cout][cin]; 1: backward-data taps w[k][cout] flipped
+};
+
+bool wino_eligible(const WinoGeom &g);
+size_t wino_ws_bytes(int C1, int C2, int Cout);
+int wino_conv(const WinoArgs &a, hipStream_t s);
+
+}  // namespace sprk

@@ -122,6 +122,81 @@ def test_conv2d_fwd_bwd(case, naive):
         close(dl[3].grad, leaves[3].grad, rel=5e-5, name=name + " gb")
 
 
+WINO_CASES = [
+    # name, N, C1, C2, H, W, Cout, pad(t,b,l,r), act, bias, backward-data on the Winograd kernel too
+    # -- every forward is large enough (>= 192 workgroups) for the Winograd F(2x2,3x3) kernel; the
+    # backward-data correlation of 96+1 inputs (97 output channels = 2 half-empty groups) stays direct
+    ("wino shift 96->96 @64", 12, 96, 0, 64, 64, 96, (2, 0, 1, 1), 1, True, True),
+    ("wino shift 96+48->96 @32", 48, 96, 48, 32, 32, 96, (2, 0, 1, 1), 1, True, True),
+    ("wino plain 96+1->96 @64", 12, 96, 1, 64, 64, 96, (1, 1, 1, 1), 1, True, False),
+    ("wino shift 48->48 @64", 12, 48, 0, 64, 64, 48, (2, 0, 1, 1), 1, True, True),
+    ("wino ragged 90->70 @8x96", 64, 90, 0, 8, 96, 70, (1, 1, 1, 1), 0, False, True),
+    ("wino up-shift 41->96 @16x32 pad(0,2,2,0)", 96, 41, 0, 16, 32, 96, (0, 2, 2, 0), 2, True, True),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
+def test_conv2d_winograd(case):
+    """The 3x3 stride-1 layers wide enough for the Winograd kernel: forward and all three gradients against
+    the fp64 CPU convolution, with the same budgets as the direct MFMA kernel (the transform adds a few fp32
+    roundings per product, far inside 2e-5 of the tensor scale), plus proof that the Winograd kernel ran."""
+    from spr_pick_amd import _lib, ops
+    name, N, C1, C2, H, W, Cout, pad, act, has_b, bwd_wino = case
+    g = torch.Generator().manual_seed(abs(hash(name)) % 10000)
+    x = torch.randn(N, C1, H, W, generator=g)
+    x2 = torch.randn(N, C2, H, W, generator=g) if C2 else None
+    w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / np.sqrt((C1 + C2) * 9)
+    b = torch.randn(Cout, generator=g) * 0.1 if has_b else None
+    d = dev()
+    L = _lib.lib()
+    dl = [t.to(d).requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
+    before = L.sprk_wino_launch_count()
+    y = ops.conv2d(dl[0], dl[2], dl[3], x2=dl[1], pad=pad, act=act)
+    assert L.sprk_wino_launch_count() == before + 1, "forward did not take the Winograd kernel"
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
+    pre = ref_conv(leaves[0], leaves[1], leaves[2], leaves[3], 0, 1, 1, pad, 0)
+    close(y, ref_conv(leaves[0], leaves[1], leaves[2], leaves[3], 0, 1, 1, pad, act), name=name + " y")
+    yr = torch.where(y.detach().cpu() > 0, pre, pre * (0.1 if act == 1 else 0.0)) if act else pre
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    y.backward(gy.to(d))
+    torch.cuda.synchronize()
+    assert L.sprk_wino_launch_count() == before + 1 + int(bwd_wino), "backward-data kernel choice"
+    close(dl[0].grad, leaves[0].grad, rel=5e-5, name=name + " gx")
+    if x2 is not None:
+        close(dl[1].grad, leaves[1].grad, rel=5e-5, name=name + " gx2")
+    close(dl[2].grad, leaves[2].grad, rel=5e-5, name=name + " gw")
+    if b is not None:
+        close(dl[3].grad, leaves[3].grad, rel=5e-5, name=name + " gb")
+
+
+def test_conv2d_winograd_affine_epilogue_and_switch():
+    """Inference epilogue relu(conv * scale + shift) on the Winograd kernel, and SPRK_WINO-independent
+    agreement with the direct MFMA kernel on the same input (sprk_set_naive routes around both)."""
+    from spr_pick_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 96, 96, 128, generator=g)
+    w = torch.randn(96, 96, 3, 3, generator=g) / 29
+    scale, shift = torch.rand(96, generator=g) + 0.5, torch.randn(96, generator=g)
+    want = F.relu(F.conv2d(F.pad(x.double(), (1, 1, 2, 0)), w.double()) * scale.double().view(1, -1, 1, 1)
+                  + shift.double().view(1, -1, 1, 1))
+    d = dev()
+    L = _lib.lib()
+    xd, wd = x.to(d), w.to(d)
+    geom = ops.make_geom(xd, None, wd, False, 1, 1, (2, 0, 1, 1))
+    before = L.sprk_wino_launch_count()
+    y = ops.conv2d_forward(xd, None, wd, geom, act=ops.ACT_RELU, scale=scale.to(d), shift=shift.to(d))
+    assert L.sprk_wino_launch_count() == before + 1
+    close(y, want, name="wino affine epilogue")
+    L.sprk_set_naive(1)
+    try:
+        y2 = ops.conv2d_forward(xd, None, wd, geom, act=ops.ACT_RELU, scale=scale.to(d), shift=shift.to(d))
+    finally:
+        L.sprk_set_naive(0)
+    assert L.sprk_wino_launch_count() == before + 1
+    close(y, y2, name="wino vs direct kernel")
+
+
 def test_conv_fused_upsample_output():
     """conv + LeakyReLU + nn.Upsample(2, nearest) fused into the stores, and its backward."""
     from spr_pick_amd import ops
