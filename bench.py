@@ -130,7 +130,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    L.sprk_prof_enable(1)          # events around the dominant kernel class only (an event pair is not free)
+    DOM = 3                        # kernel class of wino_conv_kernel<6> (include/sprk.h)
+    L.sprk_prof_enable(1 << DOM)   # events around the dominant kernel class only (an event pair is not free)
     launches0 = L.sprk_launch_count()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -152,19 +153,21 @@ def main():
         L.sprk_prof_collect(kc, ctypes.byref(n_), ctypes.byref(ms_), ctypes.byref(fl_))
         return n_.value, ms_.value, fl_.value
 
-    names = {0: "conv_mfma_kernel<4, 6>", 1: "conv_wgrad_mfma_kernel", 2: "conv_mfma_kernel<other>"}
-    prof = {0: (names[0],) + collect(0)}
+    names = {0: "conv_mfma_kernel<4, 6>", 1: "conv_wgrad_mfma_kernel", 2: "conv_mfma_kernel<other> + wino_conv_kernel<3>",
+             3: "wino_conv_kernel<6>"}
+    prof = {DOM: (names[DOM],) + collect(DOM)}
     # the other MFMA kernels: three more steps after the timed region, every class bracketed
-    L.sprk_prof_enable(7)
+    L.sprk_prof_enable(15)
     for i in range(3):
         step(args.warmup + args.steps + i)
     fence()
     L.sprk_prof_enable(0)
-    extra0 = collect(0)
-    for kc in (1, 2):
+    extra_dom = collect(DOM)
+    others = (0, 1, 2)
+    for kc in others:
         prof[kc] = (names[kc],) + collect(kc)
-    all_ms = extra0[1] + prof[1][2] + prof[2][2]
-    all_fl = extra0[2] + prof[1][3] + prof[2][3]
+    all_ms = extra_dom[1] + sum(prof[k][2] for k in others)
+    all_fl = extra_dom[2] + sum(prof[k][3] for k in others)
 
     infer = None
     if args.infer_size and rank == 0:
@@ -192,7 +195,7 @@ def main():
         return
     patches = world * args.batch * args.steps
     value = patches / dt
-    nm, n0, ms0, fl0 = prof[0]
+    nm, n0, ms0, fl0 = prof[DOM]
     achieved = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
     # HBM bytes per launch of the dominant kernel: PMC counters cannot be read in-process; they are
     # collected with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) on
@@ -200,7 +203,7 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            traffic = json.load(f)["kernels"]["conv_mfma_kernel<4, 6>"]["hbm_bytes_per_launch"]
+            traffic = json.load(f)["kernels"][nm]["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
     out = {
@@ -209,17 +212,22 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: ssdn --noise_style gaussian --noise_value var, joint mode, "
                                "64x64 patches from 4 synthetic 1024x1024 micrographs, batch %d per GPU, alpha 0.75, "
-                               "tau 0.01, Adam; fp32 MFMA convolutions" % args.batch,
+                               "tau 0.01, Adam; fp32 MFMA convolutions (Winograd F(2x2,3x3) for the wide 3x3 layers)" % args.batch,
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "patch": 64,
                    "parallelism": "dp%d (flat fp32 grad all-reduce, %d floats)" % (world, sync.numel()) if world > 1 else "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": nm, "kernel_note": "all <MT=4, NT=6, row bases, staging> instantiations",
+        "roofline": {"bound": "mfma", "kernel": nm,
+                     "kernel_note": "Winograd F(2x2,3x3) forward / backward-data of the 96-channel 3x3 layers. achieved = "
+                                    "algorithmic FLOPs of the convolution (2*N*H*W*Cout*Cin*9, SURVEY 8d) / launch time; the "
+                                    "kernel issues 4/9 of them as MFMA FLOPs, so the MFMA pipes are busy for "
+                                    "mfma_pipe_frac of the peak",
                      "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                     "mfma_pipe_frac": achieved * 4.0 / 9.0 / PEAK_FP32_MFMA_TFLOPS,
                      "launches": n0, "avg_launch_ms": ms0 / max(n0, 1)},
         "whole_step_mfma_frac": value / world * FLOP_PER_PATCH_STEP / (PEAK_FP32_MFMA_TFLOPS * 1e12),
         "other_mfma_kernels": [{"kernel": prof[k][0], "launches": prof[k][1], "avg_launch_ms": prof[k][2] / max(prof[k][1], 1),
                                 "achieved_tflops": prof[k][3] / (prof[k][2] * 1e-3) / 1e12 if prof[k][2] > 0 else 0.0}
-                               for k in (1, 2)],
+                               for k in others],
         "other_mfma_note": "three extra steps after the timed region with every MFMA launch bracketed by events",
         "all_conv_mfma_tflops": all_fl / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0,
         "kernel_launches_per_step": launches / args.steps, "final_loss": last_loss,

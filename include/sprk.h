@@ -193,11 +193,13 @@ int sprk_nms2d(const float *scores, int H, int W, int r, float threshold,
 /* ---- in-library kernel timing (bench.py's roofline leg) --------------------------------
  * sprk_prof_enable(mask): bit k set = every launch of kernel class k is bracketed by HIP events
  * on its own stream (an event pair costs the GPU front end a few microseconds, so the timed
- * region of bench.py enables class 0 only); sprk_prof_collect synchronises those events and
- * returns, per kernel class (0 = conv_mfma_kernel<4, 6, *>, the dominant forward /
- * backward-data tile shape; 1 = conv_wgrad_mfma_kernel (all instantiations); 2 = the other
- * conv_mfma_kernel instantiations), the launch count, the summed duration in ms and the
- * summed algorithmic FLOPs. */
+ * region of bench.py enables the dominant class only); sprk_prof_collect synchronises those
+ * events and returns, per kernel class (0 = conv_mfma_kernel<4, 6, *>, the widest direct
+ * forward / backward-data tile shape; 1 = conv_wgrad_mfma_kernel (all instantiations); 2 = the
+ * other conv_mfma_kernel instantiations and wino_conv_kernel<3>; 3 = wino_conv_kernel<6>, the
+ * Winograd kernel of the 96-channel 3x3 layers and the dominant kernel of a training step),
+ * the launch count, the summed duration in ms and the summed algorithmic (direct-convolution)
+ * FLOPs. */
 void sprk_prof_enable(int mask);
 int sprk_prof_collect(int kclass, long *launches, double *ms, double *flops);
 

@@ -1638,11 +1638,9 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
             return SPRK_EWORKSPACE;
         }
         sprk::WinoArgs wa{x, x2, w, ep->bias, ep->scale, ep->shift, y, (float *)ws, g->N, g->C1, g->C2, g->Hin, g->Win,
-                          g->Cout, g->pad_top, g->pad_left, ep->act, 0};
-        const int kclass = g->Cout > 48 ? kClassWino : 2;
-        sprk::prof_begin(kclass, 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * 9, s);
+                          g->Cout, g->pad_top, g->pad_left, ep->act, 0, g->Cout > 48 ? kClassWino : 2,
+                          2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * 9};
         if (int rc = sprk::wino_conv(wa, s)) return rc;
-        sprk::prof_end(kclass, s);
         return sprk::check_launch("wino_conv");
     }
     FwdPlan p;
@@ -1706,11 +1704,9 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
             return SPRK_EWORKSPACE;
         }
         sprk::WinoArgs wa{gy, nullptr, w, nullptr, nullptr, nullptr, gin, (float *)ws, g->N, g->Cout, 0, g->Hout, g->Wout,
-                          Cin, (g->KH - 1) * g->dil - g->pad_top, (g->KW - 1) * g->dil - g->pad_left, SPRK_ACT_NONE, 1};
-        const int kclass = Cin > 48 ? kClassWino : 2;
-        sprk::prof_begin(kclass, 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * 9, s);
+                          Cin, (g->KH - 1) * g->dil - g->pad_top, (g->KW - 1) * g->dil - g->pad_left, SPRK_ACT_NONE, 1,
+                          Cin > 48 ? kClassWino : 2, 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * 9};
         if (int rc = sprk::wino_conv(wa, s)) return rc;
-        sprk::prof_end(kclass, s);
         return sprk::check_launch("wino_conv(bwd_data)");
     }
     FwdPlan p;

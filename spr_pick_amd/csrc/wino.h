@@ -15,6 +15,8 @@ struct WinoArgs {
     float *U;              // workspace of wino_ws_bytes()
     int N, C1, C2, H, W, Cout, padT, padL, act;
     int mode;              // 0: forward taps w[cout][cin]; 1: backward-data taps w[k][cout] flipped
+    int kclass;            // profiling class of the main kernel launch (sprk_prof_*)
+    double flops;          // algorithmic (direct-convolution) FLOPs of this call, for the same
 };
 
 bool wino_eligible(const WinoGeom &g);

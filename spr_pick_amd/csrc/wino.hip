@@ -332,7 +332,9 @@ int wino_conv(const WinoArgs &w, hipStream_t s) {
         hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, s, a);
         return (int)SPRK_OK;
     };
+    prof_begin(w.kclass, w.flops, s);
     if (int rc = NT == 6 ? launch(wino_conv_kernel<6>) : launch(wino_conv_kernel<3>)) return rc;
+    prof_end(w.kclass, s);
     g_wino_launches.fetch_add(1, std::memory_order_relaxed);
     return SPRK_OK;
 }
