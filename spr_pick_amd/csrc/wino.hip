@@ -9,7 +9,8 @@
 // (pg, th) owns row pg of the 4x4 transform domain for the 32 tiles of half th: 4 positions x 2 pixel tiles x
 // NT channel tiles of 16x16 accumulators.  Per K-chunk of 4 input channels:
 //   * the raw input tile (10 x 40 floats per channel) and the pre-transformed weights U[pos][k][cout] arrive
-//     by buffer_load ... lds, double-buffered, one barrier per chunk;
+//     by buffer_load ... lds, double-buffered, one barrier per chunk; U is laid out [pos][nt][k][16] so
+//     that a B read is 64 consecutive floats and every operand offset is an immediate;
 //   * lane (tile l15, channel lq) reads its two raw rows and builds its own A operands in registers
 //     (row pg of B^T d, then the column pass): 8 FMAs + 8 adds per 48 MFMAs, no LDS round trip;
 //   * B operands are ds_read from U.
@@ -34,6 +35,13 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
 __device__ __forceinline__ void bdma16(rsrc_t r, int voff, int soff, float *lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds_wave_base, 16, voff, soff, 0, 0);
 }
+// LDS addresses as plain integers: one VGPR base per operand stream, everything else immediates
+typedef const __attribute__((address_space(3))) float *lds_cfp;
+__device__ __forceinline__ int lds_addr(const void *p) {
+    return (int)(unsigned)(__SIZE_TYPE__)(const __attribute__((address_space(3))) char *)p;
+}
+__device__ __forceinline__ lds_cfp lds_f(int byte_addr) { return (lds_cfp)(__SIZE_TYPE__)(unsigned)byte_addr; }
+
 __device__ __forceinline__ float act_fn(float v, int act) {
     if (act == SPRK_ACT_LEAKY) return v > 0.f ? v : v * kLeak;
     if (act == SPRK_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -48,28 +56,32 @@ constexpr int ETS = 68;                                // exchange stride per ch
 constexpr int kThreads = 512;
 constexpr int kEFloats = 4 * 2 * 32 * ETS;
 
-// U row stride: NT*16 channels padded so that the 4 k-rows of a B read fall in 4 different bank groups
-__host__ __device__ constexpr int ldw_of(int NT) { return NT == 6 ? 112 : 80; }
-__host__ __device__ constexpr int ufloats_of(int NT) { return 16 * CK * ldw_of(NT); }
+// U of one chunk: [pos][nt][k][16]: the 64 lanes of a B read (k = lane / 16, channel = lane % 16) hit 64
+// consecutive floats (no padding, no bank conflicts), and every (pos, nt) operand sits a multiple of 256 bytes
+// from the lane's base address, which is what ds_read2st64_b32 encodes as an immediate
+__host__ __device__ constexpr int ufloats_of(int NT) { return 16 * NT * CK * 16; }
 __host__ __device__ constexpr size_t lds_bytes_of(int NT) {
     return (size_t)((2 * RAWF + 2 * ufloats_of(NT)) > kEFloats ? (2 * RAWF + 2 * ufloats_of(NT)) : kEFloats) * 4;
 }
 
-// U[group][chunk][pos][k][ldw] = (G g G^T)[pos] of the tap matrix of (output channel group*NT*16 + j, GEMM-k
-// channel of chunk/k); zero rows for the channels a source's last chunk does not have, zero columns past Cout.
+// U[group][chunk][pos][nt][k][16] = (G g G^T)[pos] of the tap matrix of (output channel (group*NT + nt)*16 + j,
+// GEMM-k channel of chunk/k); zero rows for the channels a source's last chunk does not have, zero columns
+// past Cout.
 //   mode 0: g = w[cout][cin][u][v]           (forward)
 //   mode 1: g = w[k][n][2-u][2-v]            (backward-data: k = forward output channel, n = forward input)
 __global__ void wino_weights_kernel(const float *__restrict__ w, float *__restrict__ U, int Cout, int C1, int C2,
-                                    int nc1, int nch, int ldw, int npg, int groups, int mode) {
-    const long total = (long)groups * nch * CK * ldw;
+                                    int nc1, int nch, int NT, int groups, int mode) {
+    const long total = (long)groups * nch * NT * CK * 16;
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
-    const int j = e % ldw;
-    long r = e / ldw;
+    const int j = e % 16;
+    long r = e / 16;
     const int k = r % CK;
     r /= CK;
+    const int nt = r % NT;
+    r /= NT;
     const int c = r % nch, grp = r / nch;
-    const int co = grp * npg + j;   // npg = NT*16 channels per group
+    const int co = (grp * NT + nt) * 16 + j;
     int ci = -1;
     if (c < nc1) {
         if (c * CK + k < C1) ci = c * CK + k;
@@ -77,7 +89,7 @@ __global__ void wino_weights_kernel(const float *__restrict__ w, float *__restri
         ci = C1 + (c - nc1) * CK + k;
     }
     float g[3][3] = {};
-    if (ci >= 0 && j < npg && co < Cout) {
+    if (ci >= 0 && co < Cout) {
         const int Cin = C1 + C2;
         for (int t = 0; t < 9; ++t) {
             const int u = t / 3, v = t % 3;
@@ -91,11 +103,11 @@ __global__ void wino_weights_kernel(const float *__restrict__ w, float *__restri
         t4[2][v] = 0.5f * (g[0][v] - g[1][v] + g[2][v]);
         t4[3][v] = g[2][v];
     }
-    float *dst = U + (((long)grp * nch + c) * 16 * CK + k) * ldw + j;
+    float *dst = U + ((long)grp * nch + c) * (16 * NT * CK * 16) + (nt * CK + k) * 16 + j;
     for (int i = 0; i < 4; ++i) {
         const float u4[4] = {t4[i][0], 0.5f * (t4[i][0] + t4[i][1] + t4[i][2]), 0.5f * (t4[i][0] - t4[i][1] + t4[i][2]),
                              t4[i][2]};
-        for (int q = 0; q < 4; ++q) dst[(long)(i * 4 + q) * CK * ldw] = u4[q];
+        for (int q = 0; q < 4; ++q) dst[(long)(i * 4 + q) * NT * CK * 16] = u4[q];
     }
 }
 
@@ -112,7 +124,7 @@ struct KArgs {
 
 template <int NT>
 __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
-    constexpr int LDW = ldw_of(NT), UFLOATS = ufloats_of(NT);
+    constexpr int UFLOATS = ufloats_of(NT);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ub = smem;                  // 2 x UFLOATS
     float *Rb = smem + 2 * UFLOATS;    // 2 x RAWF
@@ -160,31 +172,40 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     // row pg of B^T d = d[ra] + sgn * d[rb]:  (0,2,-), (1,2,+), (2,1,-), (1,3,-)
     const int ra = pg == 0 ? 0 : pg == 2 ? 2 : 1, rb = pg == 3 ? 3 : pg == 2 ? 1 : 2;
     const float sgn = pg == 1 ? 1.f : -1.f;
-    const int rawA = lq * RPLANE + (4 * th + ra) * RP + (4 - a.padL) + 2 * l15;
-    const int rawB = lq * RPLANE + (4 * th + rb) * RP + (4 - a.padL) + 2 * l15;
-    const int boff = ((4 * pg) * CK + lq) * LDW + l15;
+    // one VGPR base per operand stream and stage, kept opaque so that every other offset is an immediate of
+    // ds_read2_b32 / ds_read2st64_b32 (no address arithmetic in the K loop)
+    int rawA[2], rawB[2];
+    rawA[0] = lds_addr(Rb + lq * RPLANE + (4 * th + ra) * RP + (4 - a.padL) + 2 * l15);
+    rawB[0] = lds_addr(Rb + lq * RPLANE + (4 * th + rb) * RP + (4 - a.padL) + 2 * l15);
+    rawA[1] = rawA[0] + RAWF * 4;
+    rawB[1] = rawB[0] + RAWF * 4;
+    int bbase = lds_addr(Ub + (4 * pg) * NT * 64 + lane);
+    asm volatile("" : "+v"(rawA[0]), "+v"(rawA[1]), "+v"(rawB[0]), "+v"(rawB[1]), "+v"(bbase));
 
     // lane (l15, lq): tiles 32 th + 16 mt + l15 of channel lq -> its A operands for the wave's 4 positions
-    auto transform = [&](const float *raw, float (&av)[2][4]) {
+    auto transform = [&](auto stage, float (&av)[2][4]) {
+        constexpr int S = decltype(stage)::value;
+        const lds_cfp pa = lds_f(rawA[S]), pb = lds_f(rawB[S]);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             float xv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                xv[j] = __builtin_fmaf(raw[rawB + mt * 2 * RP + j], sgn, raw[rawA + mt * 2 * RP + j]);
+                xv[j] = __builtin_fmaf(pb[mt * 2 * RP + j], sgn, pa[mt * 2 * RP + j]);
             av[mt][0] = xv[0] - xv[2];
             av[mt][1] = xv[1] + xv[2];
             av[mt][2] = xv[2] - xv[1];
             av[mt][3] = xv[1] - xv[3];
         }
     };
-    auto mma = [&](const float (&av)[2][4], const float *U) {
-        const float *bp = U + boff;
+    auto mma = [&](const float (&av)[2][4], auto stage) {
+        constexpr int S = decltype(stage)::value;
+        const lds_cfp bp = lds_f(bbase);
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             float bv[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[p * CK * LDW + 16 * nt];
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[S * UFLOATS + (p * NT + nt) * 64];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -200,15 +221,15 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     float aop[2][2][4];
-    transform(Rb, aop[0]);
+    transform(IC<0>{}, aop[0]);
     __syncthreads();
     // iteration c: aop[c&1] = operands of chunk c, U[c&1] holds chunk c, raw[(c+1)&1] the raw tile of chunk c+1
     auto iter = [&](auto par, int c) {
         constexpr int P = decltype(par)::value;
         if (c + 1 < nch) issue_u(c + 1, Ub + (1 - P) * UFLOATS);
         if (c + 2 < nch) issue_raw(c + 2, Rb + P * RAWF);
-        transform(Rb + (1 - P) * RAWF, aop[1 - P]);   // past the last chunk this reads a stale tile: never used
-        mma(aop[P], Ub + P * UFLOATS);
+        transform(IC<1 - P>{}, aop[1 - P]);   // past the last chunk this reads a stale tile: never used
+        mma(aop[P], IC<P>{});
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
@@ -312,10 +333,9 @@ int wino_conv(const WinoArgs &w, hipStream_t s) {
         set_error("wino_conv: tensors must be 16-byte aligned");
         return SPRK_EINVAL;
     }
-    const int ldw = ldw_of(NT);
-    const long total = (long)groups * a.nch * CK * ldw;
+    const long total = (long)groups * a.nch * NT * CK * 16;
     hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w.w, w.U, w.Cout, w.C1, w.C2, a.nc1,
-                       a.nch, ldw, NT * 16, groups, w.mode);
+                       a.nch, NT, groups, w.mode);
     if (int rc = check_launch("wino_weights")) return rc;
     const dim3 grid(a.tilesX * a.tilesY * w.N, groups);
     const size_t lds = lds_bytes_of(NT);
