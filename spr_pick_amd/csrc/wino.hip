@@ -24,6 +24,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int kXZero = (int)0x80000000;   // beyond num_records: the DMA writes zeros
@@ -251,15 +252,17 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
             const int nt = pass * 2 + n2;
             if (nt < NT) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < 2; ++mt) {
+                    // packed adds on the accumulator quads; same association as the scalar form
+                    const f32x4 s0 = (acc[0][mt][nt] + acc[1][mt][nt]) + acc[2][mt][nt];
+                    const f32x4 s1 = (acc[1][mt][nt] - acc[2][mt][nt]) - acc[3][mt][nt];
+                    float *e = E + ((pg * 2) * 32 + n2 * 16 + l15) * ETS + lq + 16 * mt + 32 * th;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float m0 = acc[0][mt][nt][r], m1 = acc[1][mt][nt][r], m2 = acc[2][mt][nt][r],
-                                    m3 = acc[3][mt][nt][r];
-                        float *e = E + ((pg * 2) * 32 + n2 * 16 + l15) * ETS + lq + 4 * r + 16 * mt + 32 * th;
-                        e[0] = m0 + m1 + m2;
-                        e[32 * ETS] = m1 - m2 - m3;
+                        e[4 * r] = s0[r];
+                        e[32 * ETS + 4 * r] = s1[r];
                     }
+                }
             }
         }
         __syncthreads();
@@ -268,11 +271,12 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
             const int cp = wave + 8 * it;   // channel within the pass
             const int co = grp * (NT * 16) + pass * 32 + cp;
             if (pass * 32 + cp < NT * 16 && co < a.Cout) {
-                float s[4][2];
+                f32x2 s[4];
 #pragma unroll
-                for (int w = 0; w < 4; ++w)
-#pragma unroll
-                    for (int bb = 0; bb < 2; ++bb) s[w][bb] = E[((w * 2 + bb) * 32 + cp) * ETS + tprime];
+                for (int w = 0; w < 4; ++w) {
+                    s[w][0] = E[((w * 2 + 0) * 32 + cp) * ETS + tprime];
+                    s[w][1] = E[((w * 2 + 1) * 32 + cp) * ETS + tprime];
+                }
                 float sc = 1.f, sh = 0.f;
                 if (a.scale) {
                     sc = a.scale[co];
@@ -280,15 +284,18 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
                 } else if (a.bias) {
                     sh = a.bias[co];
                 }
-                float2 o0 = make_float2((s[0][0] + s[1][0]) + s[2][0], (s[0][1] + s[1][1]) + s[2][1]);
-                float2 o1 = make_float2((s[1][0] - s[2][0]) - s[3][0], (s[1][1] - s[2][1]) - s[3][1]);
-                o0.x = act_fn(o0.x * sc + sh, a.act);
-                o0.y = act_fn(o0.y * sc + sh, a.act);
-                o1.x = act_fn(o1.x * sc + sh, a.act);
-                o1.y = act_fn(o1.y * sc + sh, a.act);
+                f32x2 o0 = ((s[0] + s[1]) + s[2]) * sc + sh;
+                f32x2 o1 = ((s[1] - s[2]) - s[3]) * sc + sh;
+                if (a.act == SPRK_ACT_LEAKY) {   // max(v, 0.1 v) = v > 0 ? v : 0.1 v
+                    o0 = __builtin_elementwise_max(o0, o0 * kLeak);
+                    o1 = __builtin_elementwise_max(o1, o1 * kLeak);
+                } else if (a.act == SPRK_ACT_RELU) {
+                    o0 = __builtin_elementwise_max(o0, (f32x2){0.f, 0.f});
+                    o1 = __builtin_elementwise_max(o1, (f32x2){0.f, 0.f});
+                }
                 float *yp = a.y + (((long)n * a.Cout + co) * a.H + oy) * a.W + ox;
-                *reinterpret_cast<float2 *>(yp) = o0;
-                *reinterpret_cast<float2 *>(yp + a.W) = o1;
+                *reinterpret_cast<f32x2 *>(yp) = o0;
+                *reinterpret_cast<f32x2 *>(yp + a.W) = o1;
             }
         }
         __syncthreads();
