@@ -127,11 +127,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import ctypes
+
+    def collect(kc):
+        n_, ms_, fl_ = ctypes.c_long(), ctypes.c_double(), ctypes.c_double()
+        L.sprk_prof_collect(kc, ctypes.byref(n_), ctypes.byref(ms_), ctypes.byref(fl_))
+        return n_.value, ms_.value, fl_.value
+
+    # kernel classes of include/sprk.h; the roofline leg goes to the class that takes the most GPU time in the
+    # warm-up steps (all classes bracketed there; an event pair is not free, so the timed region brackets one)
+    names = {0: "conv_mfma_kernel<4, 6>", 1: "conv_wgrad_mfma_kernel", 2: "conv_mfma_kernel<other> + wino_conv_kernel<3>",
+             3: "wino_conv_kernel<6>"}
+    notes = {
+        0: "direct implicit-GEMM forward / backward-data, all <MT=4, NT=6, row bases, staging> instantiations",
+        1: "backward-weight, all instantiations (the largest kernel family of the step; wino_conv_kernel<6> is the "
+           "largest single forward/backward-data kernel, see other_mfma_kernels)",
+        2: "the narrow / small direct instantiations and the 48-channel Winograd kernel",
+        3: "Winograd F(2x2,3x3) forward / backward-data of the 96-channel 3x3 layers. achieved = algorithmic FLOPs of "
+           "the convolution (2*N*H*W*Cout*Cin*9, SURVEY 8d) / launch time; the kernel issues 4/9 of them as MFMA "
+           "FLOPs (mfma_pipe_frac = achieved * 4/9 / peak)",
+    }
+    L.sprk_prof_enable(15)
     for i in range(args.warmup):
         step(i)
     fence()
-    DOM = 3                        # kernel class of wino_conv_kernel<6> (include/sprk.h)
-    L.sprk_prof_enable(1 << DOM)   # events around the dominant kernel class only (an event pair is not free)
+    L.sprk_prof_enable(0)
+    warm = {kc: collect(kc) for kc in names}
+    DOM = max(names, key=lambda kc: warm[kc][1]) if args.warmup > 0 else 1
+    L.sprk_prof_enable(1 << DOM)   # events around the dominant kernel class only
     launches0 = L.sprk_launch_count()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -146,15 +169,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    import ctypes
-
-    def collect(kc):
-        n_, ms_, fl_ = ctypes.c_long(), ctypes.c_double(), ctypes.c_double()
-        L.sprk_prof_collect(kc, ctypes.byref(n_), ctypes.byref(ms_), ctypes.byref(fl_))
-        return n_.value, ms_.value, fl_.value
-
-    names = {0: "conv_mfma_kernel<4, 6>", 1: "conv_wgrad_mfma_kernel", 2: "conv_mfma_kernel<other> + wino_conv_kernel<3>",
-             3: "wino_conv_kernel<6>"}
     prof = {DOM: (names[DOM],) + collect(DOM)}
     # the other MFMA kernels: three more steps after the timed region, every class bracketed
     L.sprk_prof_enable(15)
@@ -163,7 +177,7 @@ def main():
     fence()
     L.sprk_prof_enable(0)
     extra_dom = collect(DOM)
-    others = (0, 1, 2)
+    others = tuple(k for k in names if k != DOM)
     for kc in others:
         prof[kc] = (names[kc],) + collect(kc)
     all_ms = extra_dom[1] + sum(prof[k][2] for k in others)
@@ -215,15 +229,12 @@ def main():
                                "tau 0.01, Adam; fp32 MFMA convolutions (Winograd F(2x2,3x3) for the wide 3x3 layers)" % args.batch,
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "patch": 64,
                    "parallelism": "dp%d (flat fp32 grad all-reduce, %d floats)" % (world, sync.numel()) if world > 1 else "single GPU"},
-        "roofline": {"bound": "mfma", "kernel": nm,
-                     "kernel_note": "Winograd F(2x2,3x3) forward / backward-data of the 96-channel 3x3 layers. achieved = "
-                                    "algorithmic FLOPs of the convolution (2*N*H*W*Cout*Cin*9, SURVEY 8d) / launch time; the "
-                                    "kernel issues 4/9 of them as MFMA FLOPs, so the MFMA pipes are busy for "
-                                    "mfma_pipe_frac of the peak",
-                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                     "mfma_pipe_frac": achieved * 4.0 / 9.0 / PEAK_FP32_MFMA_TFLOPS,
-                     "launches": n0, "avg_launch_ms": ms0 / max(n0, 1)},
+        "roofline": dict({"bound": "mfma", "kernel": nm, "kernel_note": notes[DOM],
+                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                          "launches": n0, "avg_launch_ms": ms0 / max(n0, 1),
+                          "gpu_time_share_in_warmup": warm[DOM][1] / max(sum(w[1] for w in warm.values()), 1e-9)},
+                         **({"mfma_pipe_frac": achieved * 4.0 / 9.0 / PEAK_FP32_MFMA_TFLOPS} if DOM == 3 else {})),
         "whole_step_mfma_frac": value / world * FLOP_PER_PATCH_STEP / (PEAK_FP32_MFMA_TFLOPS * 1e12),
         "other_mfma_kernels": [{"kernel": prof[k][0], "launches": prof[k][1], "avg_launch_ms": prof[k][2] / max(prof[k][1], 1),
                                 "achieved_tflops": prof[k][3] / (prof[k][2] * 1e-3) / 1e12 if prof[k][2] > 0 else 0.0}
