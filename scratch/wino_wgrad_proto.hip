@@ -22,15 +22,25 @@ __device__ __forceinline__ void bdma16(rsrc_t r, int voff, int soff, float *lds_
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
+typedef const __attribute__((address_space(3))) float *lds_cfp;
+__device__ __forceinline__ int lds_addr(const void *p) {
+    return (int)(unsigned)(__SIZE_TYPE__)(const __attribute__((address_space(3))) char *)p;
+}
+__device__ __forceinline__ lds_cfp lds_f(int byte_addr) { return (lds_cfp)(__SIZE_TYPE__)(unsigned)byte_addr; }
+
 constexpr int CIG = 48, COG = 96;        // input channels per workgroup (grid.y groups), output channels
 constexpr int RH = 4, RW = 16;           // region: output pixels per stage (2 x 8 tiles of one image)
 constexpr int RP = 24;                   // raw row pitch (floats): columns x0-4 .. x0+19
-constexpr int PA = 148, PB = 68;         // plane strides: 6 x 24 + 4, 4 x 16 + 4
-constexpr int NA4 = CIG * (PA / 4), NB4 = COG * (PB / 4);   // DMA lanes per stage: 1776, 1632
+// LDS layouts, chosen so that every operand of a k-step is within ds_read2_b32's 1020-byte immediate range of
+// one base register per (operand row, stage):
+//   raw d : [l15 (16)][row (6)][mt (3)][24 floats]  + 4 pad  -> channel 16 mt + l15; slot stride 436 = 4 * odd
+//   dY    : [h (2)][l15 (16)][row (4)][nt (3)][16 floats] + 4 pad -> channel 48 h + 16 nt + l15; stride 196
+constexpr int PA = 6 * 3 * RP + 4, PB = 4 * 3 * 16 + 4;
+constexpr int NA4 = 16 * (PA / 4), NB4 = 32 * (PB / 4);   // DMA lanes per stage: 1744, 1568
 constexpr int AF = 4 * 2048, BF = 4 * 2048;                 // floats reserved per stage and operand (4 sweeps)
 constexpr int STAGE = AF + BF;
 constexpr int kThreads = 512;
-constexpr size_t kLdsBytes = (size_t)2 * STAGE * 4;
+constexpr size_t kLdsBytes = (size_t)(2 * STAGE + 8 * kThreads) * 4;   // two stages + the DMA lane table
 
 template <int V>
 struct IC {
@@ -49,17 +59,23 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad(const float *__restric
     const long HW = (long)H * W;
     const int nregions = N * regionsY * regionsX;
 
-    // DMA lane geometry (fixed): raw plane lanes and dY plane lanes of the 4 sweeps
-    int aoffl[4], arow[4], acol[4], boffl[4];
+    // DMA lane geometry (fixed): raw plane lanes and dY plane lanes of the 4 sweeps; rc packs the raw row
+    // (pad lanes: a row that is never inside the image) and the column offset of the lane's 4 floats
+    // byte offsets are multiples of 16: the raw row (7 = pad lane, never inside the image) rides in the low bits
+    // of aoffl, the raw column group in the low bits of boffl
+    // They live in LDS (8 words per thread): registers are the scarce resource of this kernel.
+    int *geo = reinterpret_cast<int *>(smem + 2 * STAGE) + tid;
 #pragma unroll
     for (int rd = 0; rd < 4; ++rd) {
         const int q = tid + rd * kThreads;
-        const int ch = q / 37, rem = q % 37;
-        arow[rd] = (q < NA4 && rem < 36) ? rem / 6 : -100000;   // row inside the raw tile (pad lanes: never valid)
-        acol[rd] = 4 * (rem % 6) - 4;
-        aoffl[rd] = (int)((ch * HW + (long)(rem / 6) * W + 4 * (rem % 6)) * 4);
-        const int chb = q / 17, remb = q % 17;
-        boffl[rd] = (q < NB4 && remb < 16) ? (int)((chb * HW + (long)(remb / 4) * W + 4 * (remb % 4)) * 4) : kXZero;
+        const int sl = q / (PA / 4), rem = q % (PA / 4);          // slot l15, position inside
+        const int row = rem / 18, mt = (rem % 18) / 6, c4 = rem % 6;
+        const bool va = q < NA4 && rem < 108;
+        geo[(2 * rd) * kThreads] = (int)(((16 * mt + sl) * HW + (long)row * W + 4 * c4) * 4) | (va ? row : 15);
+        const int sb = q / (PB / 4), remb = q % (PB / 4);         // slot (h, l15)
+        const int rowb = remb / 12, ntb = (remb % 12) / 4, c4b = remb % 4;
+        const int chb = (sb >> 4) * 48 + 16 * ntb + (sb & 15);
+        geo[(2 * rd + 1) * kThreads] = ((q < NB4 && remb < 48) ? (int)((chb * HW + (long)rowb * W + 4 * c4b) * 4) : kXZero) | c4;
     }
     auto issue = [&](int region, float *st) {
         int r = region;
@@ -72,10 +88,13 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad(const float *__restric
         const rsrc_t ra = make_rsrc(xa), rb = make_rsrc(gb);
 #pragma unroll
         for (int rd = 0; rd < 4; ++rd) {
-            const int gyy = y0 - pt + arow[rd], gxx = x0 + acol[rd];
-            const bool ok = gyy >= 0 && gyy < H && gxx >= 0 && gxx < W;
-            bdma16(ra, ok ? aoffl[rd] : kXZero, 0, st + rd * 2048 + wave * 256);
-            bdma16(rb, boffl[rd], 0, st + AF + rd * 2048 + wave * 256);
+            const int pa_ = geo[(2 * rd) * kThreads], pb_ = geo[(2 * rd + 1) * kThreads];
+            // row 15 (pad lane) lands far outside the image for any y0
+            const unsigned gyy = (unsigned)(y0 - pt + ((pa_ & 15) == 15 ? 0x100000 : (pa_ & 15)));
+            const unsigned gxx = (unsigned)(x0 - 4 + 4 * (pb_ & 15));
+            const bool ok = gyy < (unsigned)H && gxx < (unsigned)W;
+            bdma16(ra, ok ? (pa_ & ~15) : kXZero, 0, st + rd * 2048 + wave * 256);
+            bdma16(rb, pb_ & ~15, 0, st + AF + rd * 2048 + wave * 256);
         }
     };
 
@@ -95,19 +114,27 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad(const float *__restric
     const float zs = pg == 1 ? 1.f : -1.f;
     const int zrow = pg == 3 ? 1 : 0;
     const bool zmix = pg == 1 || pg == 2;
-    const int abase = l15 * PA + (4 - pl) + 2 * lq;           // + mt*16*PA + (2*trow + r)*RP + 8*(ks&1) ...
-    const int bbase = AF + (h * 48 + l15) * PB + 2 * lq;      // + nt*16*PB + (2*trow + r)*RW + 8*(ks&1)
+    // one VGPR base per operand stream and stage (kept opaque), every other offset an immediate
+    int baseA[2], baseB2[2], baseB[2];
+#pragma unroll
+    for (int sgi = 0; sgi < 2; ++sgi) {
+        baseA[sgi] = lds_addr(smem + sgi * STAGE + l15 * PA + ra_ * 3 * RP + (4 - pl) + 2 * lq);
+        baseB2[sgi] = lds_addr(smem + sgi * STAGE + l15 * PA + rb_ * 3 * RP + (4 - pl) + 2 * lq);
+        baseB[sgi] = lds_addr(smem + sgi * STAGE + AF + (h * 16 + l15) * PB + zrow * 48 + 2 * lq);
+    }
+    asm volatile("" : "+v"(baseA[0]), "+v"(baseA[1]), "+v"(baseB2[0]), "+v"(baseB2[1]), "+v"(baseB[0]), "+v"(baseB[1]));
 
-    auto kstep = [&](const float *st, int ks) {
-        const int trow = ks >> 1, tcol = 8 * (ks & 1);   // tiles 4 ks .. 4 ks + 3: tile row, first column (floats)
+    auto kstep = [&](auto stage, auto kstp) {
+        constexpr int S = decltype(stage)::value, ks = decltype(kstp)::value;
+        constexpr int trow = ks >> 1, tcol = 8 * (ks & 1);   // tiles 4 ks .. 4 ks + 3: tile row, first column
+        const lds_cfp pa = lds_f(baseA[S]), pb = lds_f(baseB2[S]), pz = lds_f(baseB[S]);
         float av[3][4], bv[3][4];
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) {
-            const float *pa = st + abase + mt * 16 * PA + (2 * trow + ra_) * RP + tcol;
-            const float *pb = st + abase + mt * 16 * PA + (2 * trow + rb_) * RP + tcol;
+            const int o = mt * RP + 2 * trow * 3 * RP + tcol;
             float xv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xv[j] = __builtin_fmaf(pb[j], sgn, pa[j]);
+            for (int j = 0; j < 4; ++j) xv[j] = __builtin_fmaf(pb[o + j], sgn, pa[o + j]);
             av[mt][0] = xv[0] - xv[2];
             av[mt][1] = xv[1] + xv[2];
             av[mt][2] = xv[2] - xv[1];
@@ -115,11 +142,11 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad(const float *__restric
         }
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
-            const float *p0 = st + bbase + nt * 16 * PB + (2 * trow + zrow) * RW + tcol;
-            float z0 = p0[0], z1 = p0[1];
+            const int o = nt * 16 + 2 * trow * 48 + tcol;
+            float z0 = pz[o], z1 = pz[o + 1];
             if (zmix) {
-                z0 = __builtin_fmaf(p0[RW], zs, z0);
-                z1 = __builtin_fmaf(p0[RW + 1], zs, z1);
+                z0 = __builtin_fmaf(pz[o + 48], zs, z0);
+                z1 = __builtin_fmaf(pz[o + 48 + 1], zs, z1);
             }
             bv[nt][0] = z0;
             bv[nt][1] = z0 + z1;
@@ -134,18 +161,25 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad(const float *__restric
                 for (int nt = 0; nt < 3; ++nt)
                     acc[p][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][p], bv[nt][p], acc[p][mt][nt], 0, 0, 0);
     };
+    auto stage_body = [&](auto stage, int region) {
+        constexpr int S = decltype(stage)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (region + (int)gridDim.x < nregions) issue(region + gridDim.x, smem + (1 - S) * STAGE);
+        kstep(stage, IC<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(stage, IC<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(stage, IC<2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(stage, IC<3>{});
+    };
 
     int region = blockIdx.x;
     if (region < nregions) issue(region, smem);
-    int par = 0;
-    for (; region < nregions; region += gridDim.x) {
-        float *st = smem + par * STAGE;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (region + (int)gridDim.x < nregions) issue(region + gridDim.x, smem + (1 - par) * STAGE);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) kstep(st, ks);
-        par ^= 1;
+    for (; region < nregions; region += 2 * gridDim.x) {
+        stage_body(IC<0>{}, region);
+        if (region + (int)gridDim.x < nregions) stage_body(IC<1>{}, region + gridDim.x);
     }
     __syncthreads();
 
