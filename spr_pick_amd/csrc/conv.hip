@@ -1740,9 +1740,11 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
 
 size_t sprk_conv2d_bwd_weight_ws_bytes(const sprk_conv_geom *g) {
     if (!g) return 0;
+    const size_t wino = sprk::wino_wgrad_eligible(wino_geom_fwd(g, nullptr))
+                            ? sprk::wino_wgrad_ws_bytes(g->C1, g->C2, g->Cout) : 0;
     WgPlan p;
-    if (!plan_wgrad(g, &p)) return 0;
-    return p.wsBytes;
+    if (!plan_wgrad(g, &p)) return wino;
+    return std::max(p.wsBytes, wino);
 }
 
 int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, float *gw, const sprk_conv_geom *g,
@@ -1752,6 +1754,16 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     SPRK_REQUIRE(g->C2 == 0 || x2, "conv2d_bwd_weight: C2 > 0 but x2 is null");
     hipStream_t s = (hipStream_t)stream;
     const int Cin = g->C1 + g->C2;
+    if (!sprk::g_naive && sprk::wino_wgrad_eligible(wino_geom_fwd(g, nullptr))) {
+        const size_t need = sprk::wino_wgrad_ws_bytes(g->C1, g->C2, g->Cout);
+        if (ws_bytes < need || !ws) {
+            sprk::set_error("conv2d_bwd_weight: workspace %zu < %zu", ws_bytes, need);
+            return SPRK_EWORKSPACE;
+        }
+        sprk::WinoWgArgs wa{x, x2, gy, gw, (float *)ws, g->N, g->C1, g->C2, g->Hin, g->Win, g->Cout, g->pad_top, g->pad_left, 1,
+                            2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * 9};
+        return sprk::wino_wgrad(wa, s);
+    }
     WgPlan p;
     const bool ok = plan_wgrad(g, &p);
     if (sprk::g_naive || !ok) {

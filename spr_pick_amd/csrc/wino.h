@@ -19,7 +19,19 @@ struct WinoArgs {
     double flops;          // algorithmic (direct-convolution) FLOPs of this call, for the same
 };
 
+struct WinoWgArgs {
+    const float *x, *x2, *gy;   // sources [N,C1,H,W], [N,C2,H,W] (x2 may be null), output gradient [N,Cout,H,W]
+    float *gw;                  // [Cout][C1+C2][3][3]
+    float *partial;             // workspace of wino_wgrad_ws_bytes()
+    int N, C1, C2, H, W, Cout, padT, padL;
+    int kclass;
+    double flops;
+};
+
 bool wino_eligible(const WinoGeom &g);
+bool wino_wgrad_eligible(const WinoGeom &g);
+size_t wino_wgrad_ws_bytes(int C1, int C2, int Cout);
+int wino_wgrad(const WinoWgArgs &a, hipStream_t s);
 size_t wino_ws_bytes(int C1, int C2, int Cout);
 int wino_conv(const WinoArgs &a, hipStream_t s);
 

@@ -302,6 +302,217 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Winograd backward-weight:  dW = G^T [ sum over images and 2x2 tiles of (A dY A^T) .* (B^T d B) ] G
+// 16 independent [Cin x tiles].[tiles x Cout] GEMMs (one per position of the 4x4 transform domain), the
+// reduced dimension is the tile index (k = 4 tiles per MFMA step).  Both operands are transformed in registers
+// from raw LDS tiles: lane (l15 = input channel, lq = tile) builds its A operands exactly as in the forward
+// kernel, lane (lq = tile, l15 = output channel) its B operands (row pg of A dY, then the column pass; the two
+// minus signs of A are folded into the final transform).  Workgroup = 8 waves (pg = row of the transform
+// domain, h = half of the 96 output channels), 16*MT input channels (grid.y groups), accumulators
+// 4 positions x MT x 3 tiles; it walks regions of 4 x 16 output pixels (16 tiles = 4 k-steps) of all images,
+// grid.x-strided, double-buffered by buffer_load ... lds, and leaves a partial dW per grid.x for a fixed-order
+// reduction.  LDS layouts keep every operand of a k-step within ds_read2_b32's 1020-byte immediate range of one
+// base register per (operand row, stage):
+//   raw d : [l15 (16)][row (6)][mt (MT)][24 floats] + 4 pad  -> channel 16 mt + l15
+//   dY    : [h (2)][l15 (16)][row (4)][nt (3)][16 floats] + 4 pad -> channel 48 h + 16 nt + l15
+// ------------------------------------------------------------------------------------------
+constexpr int WRH = 4, WRW = 16, WRP = 24;
+constexpr int WPB = 4 * 3 * 16 + 4;
+constexpr int WAF = 4 * 2048, WSTAGE = 2 * WAF;
+constexpr size_t kWgLdsBytes = (size_t)(2 * WSTAGE + 8 * kThreads) * 4;   // two stages + the DMA lane table
+
+struct WgKArgs {
+    const float *x, *gy;
+    float *partial;         // [parts][Cout][CinTot][9]
+    int N, Csrc, cbase, ci0, CinTot, H, W, Cout, padT, padL, regionsX, regionsY;   // cbase: first channel of group 0
+};
+
+template <int MT>
+__global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a) {
+    constexpr int PA = 6 * MT * WRP + 4, NA4 = 16 * (PA / 4), NB4 = 32 * (WPB / 4);
+    static_assert(16 * PA <= WAF && 32 * WPB <= WAF, "stage holds both operands");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15,
+              lq = lane >> 4;
+    const int pg = wave & 3, h = wave >> 2;
+    const int grp = blockIdx.y;
+    const int H = a.H, W = a.W;
+    const long HW = (long)H * W;
+    const int nregions = a.N * a.regionsY * a.regionsX;
+    const int c0 = a.cbase + grp * 16 * MT;   // first channel of this group inside the source
+    const int have = a.Csrc - c0;             // valid channels of this group
+
+    // DMA lane table (fixed per workgroup), kept in LDS: registers are the scarce resource here.  Byte offsets
+    // are multiples of 16: the raw row (15 = pad lane / missing channel, never inside the image) rides in the low
+    // bits of the raw entry, the raw column group in the low bits of the dY entry.
+    int *geo = reinterpret_cast<int *>(smem + 2 * WSTAGE) + tid;
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+        const int q = tid + rd * kThreads;
+        const int sl = q / (PA / 4), rem = q % (PA / 4);
+        const int row = rem / (6 * MT), mt = (rem % (6 * MT)) / 6, c4 = rem % 6;
+        const bool va = q < NA4 && rem < 36 * MT && 16 * mt + sl < have;
+        geo[(2 * rd) * kThreads] = (int)(((16 * mt + sl) * HW + (long)row * W + 4 * c4) * 4) | (va ? row : 15);
+        const int sb = q / (WPB / 4), remb = q % (WPB / 4);
+        const int rowb = remb / 12, ntb = (remb % 12) / 4, c4b = remb % 4;
+        const int chb = (sb >> 4) * 48 + 16 * ntb + (sb & 15);
+        geo[(2 * rd + 1) * kThreads] =
+            ((q < NB4 && remb < 48 && chb < a.Cout) ? (int)((chb * HW + (long)rowb * W + 4 * c4b) * 4) : kXZero) | c4;
+    }
+    auto issue = [&](int region, float *st) {
+        int r = region;
+        const int rx = r % a.regionsX;
+        r /= a.regionsX;
+        const int ry = r % a.regionsY, n = r / a.regionsY;
+        const int y0 = ry * WRH, x0 = rx * WRW;
+        const float *xa = a.x + ((long)n * a.Csrc + c0) * HW + (long)(y0 - a.padT) * W + (x0 - 4);
+        const float *gb = a.gy + (long)n * a.Cout * HW + (long)y0 * W + x0;
+        const rsrc_t ra = make_rsrc(xa), rb = make_rsrc(gb);
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+            const int pa_ = geo[(2 * rd) * kThreads], pb_ = geo[(2 * rd + 1) * kThreads];
+            const unsigned gyy = (unsigned)(y0 - a.padT + ((pa_ & 15) == 15 ? 0x100000 : (pa_ & 15)));
+            const unsigned gxx = (unsigned)(x0 - 4 + 4 * (pb_ & 15));
+            const bool ok = gyy < (unsigned)H && gxx < (unsigned)W;
+            bdma16(ra, ok ? (pa_ & ~15) : kXZero, 0, st + rd * 2048 + wave * 256);
+            bdma16(rb, pb_ & ~15, 0, st + WAF + rd * 2048 + wave * 256);
+        }
+    };
+
+    f32x4 acc[4][MT][3];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) acc[p][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ra_ = pg == 0 ? 0 : pg == 2 ? 2 : 1, rb_ = pg == 3 ? 3 : pg == 2 ? 1 : 2;
+    const float sgn = pg == 1 ? 1.f : -1.f;
+    const float zs = pg == 1 ? 1.f : -1.f;
+    const int zrow = pg == 3 ? 1 : 0;
+    const bool zmix = pg == 1 || pg == 2;
+    int baseA[2], baseB2[2], baseB[2];
+#pragma unroll
+    for (int sgi = 0; sgi < 2; ++sgi) {
+        baseA[sgi] = lds_addr(smem + sgi * WSTAGE + l15 * PA + ra_ * MT * WRP + (4 - a.padL) + 2 * lq);
+        baseB2[sgi] = lds_addr(smem + sgi * WSTAGE + l15 * PA + rb_ * MT * WRP + (4 - a.padL) + 2 * lq);
+        baseB[sgi] = lds_addr(smem + sgi * WSTAGE + WAF + (h * 16 + l15) * WPB + zrow * 48 + 2 * lq);
+    }
+    asm volatile("" : "+v"(baseA[0]), "+v"(baseA[1]), "+v"(baseB2[0]), "+v"(baseB2[1]), "+v"(baseB[0]), "+v"(baseB[1]));
+
+    auto kstep = [&](auto stage, auto kstp) {
+        constexpr int S = decltype(stage)::value, ks = decltype(kstp)::value;
+        constexpr int trow = ks >> 1, tcol = 8 * (ks & 1);   // tiles 4 ks .. 4 ks + 3: tile row, first column
+        const lds_cfp pa = lds_f(baseA[S]), pb = lds_f(baseB2[S]), pz = lds_f(baseB[S]);
+        float av[MT][4], bv[3][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int o = mt * WRP + 2 * trow * MT * WRP + tcol;
+            float xv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[j] = __builtin_fmaf(pb[o + j], sgn, pa[o + j]);
+            av[mt][0] = xv[0] - xv[2];
+            av[mt][1] = xv[1] + xv[2];
+            av[mt][2] = xv[2] - xv[1];
+            av[mt][3] = xv[1] - xv[3];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int o = nt * 16 + 2 * trow * 48 + tcol;
+            float z0 = pz[o], z1 = pz[o + 1];
+            if (zmix) {
+                z0 = __builtin_fmaf(pz[o + 48], zs, z0);
+                z1 = __builtin_fmaf(pz[o + 48 + 1], zs, z1);
+            }
+            bv[nt][0] = z0;
+            bv[nt][1] = z0 + z1;
+            bv[nt][2] = z0 - z1;
+            bv[nt][3] = z1;   // true value -z1: folded into the final transform
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt)
+                    acc[p][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][p], bv[nt][p], acc[p][mt][nt], 0, 0, 0);
+    };
+    auto stage_body = [&](auto stage, int region) {
+        constexpr int S = decltype(stage)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (region + (int)gridDim.x < nregions) issue(region + gridDim.x, smem + (1 - S) * WSTAGE);
+        kstep(stage, IC<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(stage, IC<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(stage, IC<2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(stage, IC<3>{});
+    };
+
+    int region = blockIdx.x;
+    if (region < nregions) issue(region, smem);
+    for (; region < nregions; region += 2 * gridDim.x) {
+        stage_body(IC<0>{}, region);
+        if (region + (int)gridDim.x < nregions) stage_body(IC<1>{}, region + gridDim.x);
+    }
+    __syncthreads();
+
+    // final transform dW = G^T M G: column pass (over p) in registers, row pass (over pg) through LDS.
+    // M[.][3] and M[3][.] carry a folded minus sign.
+    float *X = smem;   // X[pg][h][v][mt][r][lane], one nt at a time
+    const float s3 = pg == 3 ? -1.f : 1.f;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m0 = acc[0][mt][nt][r] * s3, m1 = acc[1][mt][nt][r] * s3, m2 = acc[2][mt][nt][r] * s3,
+                            m3 = -acc[3][mt][nt][r] * s3;
+                float *dst = X + (((pg * 2 + h) * 3 + 0) * (4 * MT) + mt * 4 + r) * 64 + lane;
+                dst[0 * 4 * MT * 64] = m0 + 0.5f * (m1 + m2);
+                dst[1 * 4 * MT * 64] = 0.5f * (m1 - m2);
+                dst[2 * 4 * MT * 64] = 0.5f * (m1 + m2) + m3;
+            }
+        __syncthreads();
+        // reader: wave (pg, h) handles items pg*3*MT .. of half h; item = (v, mt, r)
+        for (int it = 0; it < 3 * MT; ++it) {
+            const int item = pg * 3 * MT + it;
+            const int v = item / (4 * MT), mt = (item % (4 * MT)) / 4, r = item % 4;
+            float xg[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xg[i] = X[(((i * 2 + h) * 3 + v) * (4 * MT) + mt * 4 + r) * 64 + lane];
+            const int co = h * 48 + nt * 16 + l15, cl = mt * 16 + 4 * lq + r;
+            if (co < a.Cout && cl < have) {
+                float *o = a.partial + (((long)blockIdx.x * a.Cout + co) * a.CinTot + a.ci0 + c0 + cl) * 9 + v;
+                o[0] = xg[0] + 0.5f * (xg[1] + xg[2]);
+                o[3] = 0.5f * (xg[1] - xg[2]);
+                o[6] = 0.5f * (xg[1] + xg[2]) + xg[3];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void wino_wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, long n, int parts) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < parts; ++p) s += partial[(long)p * n + e];
+    gw[e] = s;
+}
+
+// channels of one source -> (groups of 48, one tail group of <= 16) or not representable
+bool wg_split(int C, int *g48, int *tail) {
+    *g48 = C / 48;
+    *tail = C % 48;
+    return *tail <= 16;
+}
+
 int nt_of(int Cout) { return Cout <= 48 ? 3 : 6; }
 
 }  // namespace
@@ -362,6 +573,80 @@ int wino_conv(const WinoArgs &w, hipStream_t s) {
     prof_begin(w.kclass, w.flops, s);
     if (int rc = NT == 6 ? launch(wino_conv_kernel<6>) : launch(wino_conv_kernel<3>)) return rc;
     prof_end(w.kclass, s);
+    g_wino_launches.fetch_add(1, std::memory_order_relaxed);
+    return SPRK_OK;
+}
+
+bool wino_wgrad_eligible(const WinoGeom &g) {
+    static const int on = getenv("SPRK_WINO_WGRAD") ? atoi(getenv("SPRK_WINO_WGRAD")) : 1;   // debug: 0 = direct kernel only
+    if (!on) return false;
+    if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.dil != 1 || g.up1) return false;
+    if (g.Hout != g.H || g.Wout != g.W || g.H % WRH || g.W % WRW) return false;
+    if (g.padL < 0 || g.padL > 4 || g.padT < 0) return false;
+    if (g.Cout < 81 || g.Cout > 96) return false;   // two halves of 3 channel tiles
+    int g48, tail;
+    if (g.C1 < 1 || !wg_split(g.C1, &g48, &tail)) return false;
+    if (g.C2 > 0 && !wg_split(g.C2, &g48, &tail)) return false;
+    if ((long)g.N * (g.H / WRH) * (g.W / WRW) < 2048) return false;   // >= 16 regions per workgroup
+    if ((long)48 * g.H * g.W * 4 >= 0x7FFFFFFFL || (long)g.Cout * g.H * g.W * 4 >= 0x7FFFFFFFL) return false;
+    return true;
+}
+
+constexpr int kWgParts = 128;
+
+size_t wino_wgrad_ws_bytes(int C1, int C2, int Cout) {
+    return (size_t)kWgParts * Cout * (C1 + C2) * 9 * sizeof(float);
+}
+
+int wino_wgrad(const WinoWgArgs &w, hipStream_t s) {
+    if ((((uintptr_t)w.x | (uintptr_t)w.x2 | (uintptr_t)w.gy | (uintptr_t)w.partial) & 15) != 0) {
+        set_error("wino_wgrad: tensors must be 16-byte aligned");
+        return SPRK_EINVAL;
+    }
+    const int CinTot = w.C1 + w.C2;
+    static bool attr3 = false, attr1 = false;
+    auto launch = [&](const float *src, int Csrc, int ci0) -> int {
+        int g48, tail;
+        wg_split(Csrc, &g48, &tail);
+        WgKArgs a{src, w.gy, w.partial, w.N, Csrc, 0, ci0, CinTot, w.H, w.W, w.Cout, w.padT, w.padL, w.W / WRW, w.H / WRH};
+        if (g48 > 0) {
+            if (!attr3) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_wgrad_kernel<3>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLdsBytes) != hipSuccess) {
+                    set_error("wino_wgrad: cannot reserve %zu bytes of LDS", kWgLdsBytes);
+                    return SPRK_ELAUNCH;
+                }
+                attr3 = true;
+            }
+            prof_begin(w.kclass, w.flops * (48.0 * g48) / CinTot, s);
+            hipLaunchKernelGGL(wino_wgrad_kernel<3>, dim3(kWgParts, g48), dim3(kThreads), kWgLdsBytes, s, a);
+            prof_end(w.kclass, s);
+            if (int rc = check_launch("wino_wgrad<3>")) return rc;
+        }
+        if (tail > 0) {
+            if (!attr1) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_wgrad_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLdsBytes) != hipSuccess) {
+                    set_error("wino_wgrad: cannot reserve %zu bytes of LDS", kWgLdsBytes);
+                    return SPRK_ELAUNCH;
+                }
+                attr1 = true;
+            }
+            WgKArgs t = a;
+            t.cbase = 48 * g48;   // the tail group sits after the 48-channel groups
+            prof_begin(w.kclass, w.flops * (double)tail / CinTot, s);
+            hipLaunchKernelGGL(wino_wgrad_kernel<1>, dim3(kWgParts, 1), dim3(kThreads), kWgLdsBytes, s, t);
+            prof_end(w.kclass, s);
+            if (int rc = check_launch("wino_wgrad<1>")) return rc;
+        }
+        return SPRK_OK;
+    };
+    if (int rc = launch(w.x, w.C1, 0)) return rc;
+    if (w.C2 > 0)
+        if (int rc = launch(w.x2, w.C2, w.C1)) return rc;
+    const long n = (long)w.Cout * CinTot * 9;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, w.partial, w.gw, n, kWgParts);
+    if (int rc = check_launch("wino_wgrad_reduce")) return rc;
     g_wino_launches.fetch_add(1, std::memory_order_relaxed);
     return SPRK_OK;
 }

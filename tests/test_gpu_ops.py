@@ -123,15 +123,20 @@ def test_conv2d_fwd_bwd(case, naive):
 
 
 WINO_CASES = [
-    # name, N, C1, C2, H, W, Cout, pad(t,b,l,r), act, bias, backward-data on the Winograd kernel too
+    # name, N, C1, C2, H, W, Cout, pad(t,b,l,r), act, bias, backward-data on the Winograd kernel, backward-weight too
     # -- every forward is large enough (>= 192 workgroups) for the Winograd F(2x2,3x3) kernel; the
-    # backward-data correlation of 96+1 inputs (97 output channels = 2 half-empty groups) stays direct
-    ("wino shift 96->96 @64", 12, 96, 0, 64, 64, 96, (2, 0, 1, 1), 1, True, True),
-    ("wino shift 96+48->96 @32", 48, 96, 48, 32, 32, 96, (2, 0, 1, 1), 1, True, True),
-    ("wino plain 96+1->96 @64", 12, 96, 1, 64, 64, 96, (1, 1, 1, 1), 1, True, False),
-    ("wino shift 48->48 @64", 12, 48, 0, 64, 64, 48, (2, 0, 1, 1), 1, True, True),
-    ("wino ragged 90->70 @8x96", 64, 90, 0, 8, 96, 70, (1, 1, 1, 1), 0, False, True),
-    ("wino up-shift 41->96 @16x32 pad(0,2,2,0)", 96, 41, 0, 16, 32, 96, (0, 2, 2, 0), 2, True, True),
+    # backward-data correlation of 96+1 inputs (97 output channels = 2 half-empty groups) stays direct; the
+    # Winograd backward-weight kernel takes 81-96 output channels, sources of 48 k (+ <= 16) channels and
+    # >= 2048 regions of 4x16 pixels
+    ("wino shift 96->96 @64", 12, 96, 0, 64, 64, 96, (2, 0, 1, 1), 1, True, True, False),
+    ("wino shift 96+48->96 @32", 48, 96, 48, 32, 32, 96, (2, 0, 1, 1), 1, True, True, False),
+    ("wino plain 96+1->96 @64", 12, 96, 1, 64, 64, 96, (1, 1, 1, 1), 1, True, False, False),
+    ("wino shift 48->48 @64", 12, 48, 0, 64, 64, 48, (2, 0, 1, 1), 1, True, True, False),
+    ("wino ragged 90->70 @8x96", 64, 90, 0, 8, 96, 70, (1, 1, 1, 1), 0, False, True, False),
+    ("wino up-shift 41->96 @16x32 pad(0,2,2,0)", 96, 41, 0, 16, 32, 96, (0, 2, 2, 0), 2, True, True, False),
+    ("wino+wgrad shift 96+1->96 @64", 32, 96, 1, 64, 64, 96, (2, 0, 1, 1), 1, True, False, True),
+    ("wino+wgrad shift 96+48->96 @32", 128, 96, 48, 32, 32, 96, (2, 0, 1, 1), 1, True, True, True),
+    ("wino+wgrad plain 48+10->88 @16x64 pad(1,1,2,0)", 130, 48, 10, 16, 64, 88, (1, 1, 2, 0), 0, True, False, True),
 ]
 
 
@@ -141,7 +146,7 @@ def test_conv2d_winograd(case):
     the fp64 CPU convolution, with the same budgets as the direct MFMA kernel (the transform adds a few fp32
     roundings per product, far inside 2e-5 of the tensor scale), plus proof that the Winograd kernel ran."""
     from spr_pick_amd import _lib, ops
-    name, N, C1, C2, H, W, Cout, pad, act, has_b, bwd_wino = case
+    name, N, C1, C2, H, W, Cout, pad, act, has_b, bwd_wino, wg_wino = case
     g = torch.Generator().manual_seed(abs(hash(name)) % 10000)
     x = torch.randn(N, C1, H, W, generator=g)
     x2 = torch.randn(N, C2, H, W, generator=g) if C2 else None
@@ -161,7 +166,7 @@ def test_conv2d_winograd(case):
     yr.backward(gy.double())
     y.backward(gy.to(d))
     torch.cuda.synchronize()
-    assert L.sprk_wino_launch_count() == before + 1 + int(bwd_wino), "backward-data kernel choice"
+    assert L.sprk_wino_launch_count() == before + 1 + int(bwd_wino) + int(wg_wino), "backward kernel choice"
     close(dl[0].grad, leaves[0].grad, rel=5e-5, name=name + " gx")
     if x2 is not None:
         close(dl[1].grad, leaves[1].grad, rel=5e-5, name=name + " gx2")
