@@ -498,9 +498,20 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a
     }
 }
 
-__global__ void wino_wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, long n, int parts) {
+// gw[co][ci][tap] = sum over the parts that wrote column ci (launches differ in their K split): up to 4 column
+// ranges [.., end[i]) with parts[i] partial results each, summed in a fixed order
+struct WgRanges {
+    int end[4], parts[4];
+};
+__global__ void wino_wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw, long n, int CinTot,
+                                         WgRanges rg) {
     const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
+    const int ci = (int)((e / 9) % CinTot);
+    int parts = rg.parts[3];
+#pragma unroll
+    for (int i = 2; i >= 0; --i)
+        if (ci < rg.end[i]) parts = rg.parts[i];
     float s = 0.f;
     for (int p = 0; p < parts; ++p) s += partial[(long)p * n + e];
     gw[e] = s;
@@ -587,12 +598,14 @@ bool wino_wgrad_eligible(const WinoGeom &g) {
     int g48, tail;
     if (g.C1 < 1 || !wg_split(g.C1, &g48, &tail)) return false;
     if (g.C2 > 0 && !wg_split(g.C2, &g48, &tail)) return false;
-    if ((long)g.N * (g.H / WRH) * (g.W / WRW) < 2048) return false;   // >= 16 regions per workgroup
+    // the partial results (256 x Cout x Cin x 9 floats written, then reduced) are a fixed cost: only layers with
+    // >= 32 regions per workgroup are worth it (64x64 patches from batch 128 up; 32x32 layers stay direct)
+    if ((long)g.N * (g.H / WRH) * (g.W / WRW) < 8192) return false;
     if ((long)48 * g.H * g.W * 4 >= 0x7FFFFFFFL || (long)g.Cout * g.H * g.W * 4 >= 0x7FFFFFFFL) return false;
     return true;
 }
 
-constexpr int kWgParts = 128;
+constexpr int kWgParts = 256;   // most partial results any launch leaves (one workgroup per CU)
 
 size_t wino_wgrad_ws_bytes(int C1, int C2, int Cout) {
     return (size_t)kWgParts * Cout * (C1 + C2) * 9 * sizeof(float);
@@ -605,6 +618,8 @@ int wino_wgrad(const WinoWgArgs &w, hipStream_t s) {
     }
     const int CinTot = w.C1 + w.C2;
     static bool attr3 = false, attr1 = false;
+    WgRanges rg{};
+    int nr = 0;
     auto launch = [&](const float *src, int Csrc, int ci0) -> int {
         int g48, tail;
         wg_split(Csrc, &g48, &tail);
@@ -618,10 +633,13 @@ int wino_wgrad(const WinoWgArgs &w, hipStream_t s) {
                 }
                 attr3 = true;
             }
+            const int parts = kWgParts / g48;   // K split: one workgroup per CU over all channel groups
             prof_begin(w.kclass, w.flops * (48.0 * g48) / CinTot, s);
-            hipLaunchKernelGGL(wino_wgrad_kernel<3>, dim3(kWgParts, g48), dim3(kThreads), kWgLdsBytes, s, a);
+            hipLaunchKernelGGL(wino_wgrad_kernel<3>, dim3(parts, g48), dim3(kThreads), kWgLdsBytes, s, a);
             prof_end(w.kclass, s);
             if (int rc = check_launch("wino_wgrad<3>")) return rc;
+            rg.end[nr] = ci0 + 48 * g48;
+            rg.parts[nr++] = parts;
         }
         if (tail > 0) {
             if (!attr1) {
@@ -638,14 +656,17 @@ int wino_wgrad(const WinoWgArgs &w, hipStream_t s) {
             hipLaunchKernelGGL(wino_wgrad_kernel<1>, dim3(kWgParts, 1), dim3(kThreads), kWgLdsBytes, s, t);
             prof_end(w.kclass, s);
             if (int rc = check_launch("wino_wgrad<1>")) return rc;
+            rg.end[nr] = ci0 + Csrc;
+            rg.parts[nr++] = kWgParts;
         }
         return SPRK_OK;
     };
     if (int rc = launch(w.x, w.C1, 0)) return rc;
     if (w.C2 > 0)
         if (int rc = launch(w.x2, w.C2, w.C1)) return rc;
+    for (int i = nr; i < 4; ++i) rg.end[i] = CinTot, rg.parts[i] = rg.parts[nr - 1];
     const long n = (long)w.Cout * CinTot * 9;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, w.partial, w.gw, n, kWgParts);
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, w.partial, w.gw, n, CinTot, rg);
     if (int rc = check_launch("wino_wgrad_reduce")) return rc;
     g_wino_launches.fetch_add(1, std::memory_order_relaxed);
     return SPRK_OK;

@@ -127,16 +127,16 @@ WINO_CASES = [
     # -- every forward is large enough (>= 192 workgroups) for the Winograd F(2x2,3x3) kernel; the
     # backward-data correlation of 96+1 inputs (97 output channels = 2 half-empty groups) stays direct; the
     # Winograd backward-weight kernel takes 81-96 output channels, sources of 48 k (+ <= 16) channels and
-    # >= 2048 regions of 4x16 pixels
+    # >= 8192 regions of 4x16 pixels
     ("wino shift 96->96 @64", 12, 96, 0, 64, 64, 96, (2, 0, 1, 1), 1, True, True, False),
     ("wino shift 96+48->96 @32", 48, 96, 48, 32, 32, 96, (2, 0, 1, 1), 1, True, True, False),
     ("wino plain 96+1->96 @64", 12, 96, 1, 64, 64, 96, (1, 1, 1, 1), 1, True, False, False),
     ("wino shift 48->48 @64", 12, 48, 0, 64, 64, 48, (2, 0, 1, 1), 1, True, True, False),
     ("wino ragged 90->70 @8x96", 64, 90, 0, 8, 96, 70, (1, 1, 1, 1), 0, False, True, False),
     ("wino up-shift 41->96 @16x32 pad(0,2,2,0)", 96, 41, 0, 16, 32, 96, (0, 2, 2, 0), 2, True, True, False),
-    ("wino+wgrad shift 96+1->96 @64", 32, 96, 1, 64, 64, 96, (2, 0, 1, 1), 1, True, False, True),
-    ("wino+wgrad shift 96+48->96 @32", 128, 96, 48, 32, 32, 96, (2, 0, 1, 1), 1, True, True, True),
-    ("wino+wgrad plain 48+10->88 @16x64 pad(1,1,2,0)", 130, 48, 10, 16, 64, 88, (1, 1, 2, 0), 0, True, False, True),
+    ("wino+wgrad shift 96+1->96 @64", 128, 96, 1, 64, 64, 96, (2, 0, 1, 1), 1, True, False, True),
+    ("wino+wgrad shift 96+48->96 @32x128", 128, 96, 48, 32, 128, 96, (2, 0, 1, 1), 1, True, True, True),
+    ("wino+wgrad plain 48+10->88 @16x256 pad(1,1,2,0)", 130, 48, 10, 16, 256, 88, (1, 1, 2, 0), 0, True, False, True),
 ]
 
 
