@@ -137,17 +137,18 @@ def main():
     # kernel classes of include/sprk.h; the roofline leg goes to the class that takes the most GPU time in the
     # warm-up steps (all classes bracketed there; an event pair is not free, so the timed region brackets one)
     names = {0: "conv_mfma_kernel<4, 6>", 1: "conv_wgrad_mfma_kernel", 2: "conv_mfma_kernel<other> + wino_conv_kernel<3>",
-             3: "wino_conv_kernel<6>"}
+             3: "wino_conv_kernel<6>", 4: "wino_wgrad_kernel"}
     notes = {
         0: "direct implicit-GEMM forward / backward-data, all <MT=4, NT=6, row bases, staging> instantiations",
-        1: "backward-weight, all instantiations (the largest kernel family of the step; wino_conv_kernel<6> is the "
-           "largest single forward/backward-data kernel, see other_mfma_kernels)",
+        1: "direct backward-weight, all instantiations",
         2: "the narrow / small direct instantiations and the 48-channel Winograd kernel",
         3: "Winograd F(2x2,3x3) forward / backward-data of the 96-channel 3x3 layers. achieved = algorithmic FLOPs of "
            "the convolution (2*N*H*W*Cout*Cin*9, SURVEY 8d) / launch time; the kernel issues 4/9 of them as MFMA "
            "FLOPs (mfma_pipe_frac = achieved * 4/9 / peak)",
+        4: "Winograd F(2x2,3x3) backward-weight of the largest layers (main and tail-channel launches); issues 4/9 "
+           "of the algorithmic FLOPs as MFMA FLOPs",
     }
-    L.sprk_prof_enable(15)
+    L.sprk_prof_enable(31)
     for i in range(args.warmup):
         step(i)
     fence()
@@ -171,7 +172,7 @@ def main():
 
     prof = {DOM: (names[DOM],) + collect(DOM)}
     # the other MFMA kernels: three more steps after the timed region, every class bracketed
-    L.sprk_prof_enable(15)
+    L.sprk_prof_enable(31)
     for i in range(3):
         step(args.warmup + args.steps + i)
     fence()
@@ -234,7 +235,7 @@ def main():
                           "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                           "launches": n0, "avg_launch_ms": ms0 / max(n0, 1),
                           "gpu_time_share_in_warmup": warm[DOM][1] / max(sum(w[1] for w in warm.values()), 1e-9)},
-                         **({"mfma_pipe_frac": achieved * 4.0 / 9.0 / PEAK_FP32_MFMA_TFLOPS} if DOM == 3 else {})),
+                         **({"mfma_pipe_frac": achieved * 4.0 / 9.0 / PEAK_FP32_MFMA_TFLOPS} if DOM in (3, 4) else {})),
         "whole_step_mfma_frac": value / world * FLOP_PER_PATCH_STEP / (PEAK_FP32_MFMA_TFLOPS * 1e12),
         "other_mfma_kernels": [{"kernel": prof[k][0], "launches": prof[k][1], "avg_launch_ms": prof[k][2] / max(prof[k][1], 1),
                                 "achieved_tflops": prof[k][3] / (prof[k][2] * 1e-3) / 1e12 if prof[k][2] > 0 else 0.0}

@@ -197,7 +197,8 @@ int sprk_nms2d(const float *scores, int H, int W, int r, float threshold,
  * events and returns, per kernel class (0 = conv_mfma_kernel<4, 6, *>, the widest direct
  * forward / backward-data tile shape; 1 = conv_wgrad_mfma_kernel (all instantiations); 2 = the
  * other conv_mfma_kernel instantiations and wino_conv_kernel<3>; 3 = wino_conv_kernel<6>, the
- * Winograd kernel of the 96-channel 3x3 layers, the largest single forward / backward-data kernel),
+ * Winograd kernel of the 96-channel 3x3 layers, the largest single kernel of a training step;
+ * 4 = wino_wgrad_kernel, the Winograd backward-weight kernel of the largest layers),
  * the launch count, the summed duration in ms and the summed algorithmic (direct-convolution)
  * FLOPs. */
 void sprk_prof_enable(int mask);

@@ -1760,8 +1760,8 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
             sprk::set_error("conv2d_bwd_weight: workspace %zu < %zu", ws_bytes, need);
             return SPRK_EWORKSPACE;
         }
-        sprk::WinoWgArgs wa{x, x2, gy, gw, (float *)ws, g->N, g->C1, g->C2, g->Hin, g->Win, g->Cout, g->pad_top, g->pad_left, 1,
-                            2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * 9};
+        sprk::WinoWgArgs wa{x, x2, gy, gw, (float *)ws, g->N, g->C1, g->C2, g->Hin, g->Win, g->Cout, g->pad_top, g->pad_left, 4,
+                            2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * 9};   // profiling class 4
         return sprk::wino_wgrad(wa, s);
     }
     WgPlan p;
