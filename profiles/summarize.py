@@ -105,7 +105,7 @@ json.dump({"note": "per-launch averages over the profiled bench run; FETCH_SIZE 
 
 mf = counters("mfma")
 json.dump({k: {cn: {"sum": v[0], "launches": v[1]} for cn, v in d.items()} for k, d in mf.items()
-           if "conv" in k}, open(os.path.join(here, tag + "_mfma_counters.json"), "w"), indent=1)
+           if "conv" in k or "wino" in k}, open(os.path.join(here, tag + "_mfma_counters.json"), "w"), indent=1)
 for name in ("bench.json", "bench_under_rocprof.json"):
     open(os.path.join(here, "%s_%s" % (tag, name)), "w").write(open(os.path.join(src, name)).read())
 print("wrote summaries for", tag)
