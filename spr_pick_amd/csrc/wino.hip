@@ -33,6 +33,12 @@ constexpr float kLeak = 0.1f;
 __device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7FFFFFFF, 0x00020000);
 }
+// a wave-uniform pointer that the compiler computed on the vector ALU (64-bit multiplies): back into SGPRs
+__device__ __forceinline__ const float *uniform_ptr(const float *p) {
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const float *)(((unsigned long)hi << 32) | lo);
+}
 __device__ __forceinline__ void bdma16(rsrc_t r, int voff, int soff, float *lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds_wave_base, 16, voff, soff, 0, 0);
 }
@@ -361,14 +367,17 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a
             ((q < NB4 && remb < 48 && chb < a.Cout) ? (int)((chb * HW + (long)rowb * W + 4 * c4b) * 4) : kXZero) | c4;
     }
     auto issue = [&](int region, float *st) {
-        int r = region;
-        const int rx = r % a.regionsX;
-        r /= a.regionsX;
-        const int ry = r % a.regionsY, n = r / a.regionsY;
+        // wave-uniform, but integer division runs on the vector ALU: pull the results back into SGPRs so that
+        // the buffer descriptors are scalar (otherwise every DMA sits in a waterfall loop)
+        const int r0 = __builtin_amdgcn_readfirstlane(region);
+        const int q0 = __builtin_amdgcn_readfirstlane(r0 / a.regionsX);
+        const int rx = r0 - q0 * a.regionsX;
+        const int n = __builtin_amdgcn_readfirstlane(q0 / a.regionsY);
+        const int ry = q0 - n * a.regionsY;
         const int y0 = ry * WRH, x0 = rx * WRW;
         const float *xa = a.x + ((long)n * a.Csrc + c0) * HW + (long)(y0 - a.padT) * W + (x0 - 4);
         const float *gb = a.gy + (long)n * a.Cout * HW + (long)y0 * W + x0;
-        const rsrc_t ra = make_rsrc(xa), rb = make_rsrc(gb);
+        const rsrc_t ra = make_rsrc(uniform_ptr(xa)), rb = make_rsrc(uniform_ptr(gb));
 #pragma unroll
         for (int rd = 0; rd < 4; ++rd) {
             const int pa_ = geo[(2 * rd) * kThreads], pb_ = geo[(2 * rd + 1) * kThreads];
