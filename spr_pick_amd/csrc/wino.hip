@@ -56,9 +56,16 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 }
 
 constexpr int CK = 4;                                  // channels per chunk = one MFMA k-step per position
-constexpr int TR = 8, TC = 32;                         // output pixels per workgroup
-constexpr int RP = 40, RPLANE = (TR + 2) * RP;         // raw tile: 10 rows x 40 columns, 16-byte column groups
-constexpr int RAWF = 1792;                             // 4 planes = 400 DMA lanes -> 7 waves x 256 floats
+// Workgroup geometry: 64 tiles as 4 x 16 (8 x 32 output pixels; images whose width is a multiple of 32) or as
+// 8 x 8 (16 x 16 output pixels; widths that are only a multiple of 16, e.g. the 16 x 16 U-Net level)
+template <int SQ>
+struct Geo {
+    static constexpr int TR = SQ ? 16 : 8, TC = SQ ? 16 : 32;   // output pixels per workgroup
+    static constexpr int RP = TC + 8, RPLANE = (TR + 2) * RP;   // raw tile rows x columns (16-byte column groups)
+    static constexpr int LGTX = SQ ? 3 : 4;                     // log2 of the tiles per tile row
+};
+constexpr int RAWF = 1792;                             // 4 planes = 400 / 432 DMA lanes -> 7 waves x 256 floats
+static_assert(CK * Geo<0>::RPLANE <= RAWF && CK * Geo<1>::RPLANE <= RAWF, "raw tile fits its stage");
 constexpr int ETS = 68;                                // exchange stride per channel: 64 tiles + 4
 constexpr int kThreads = 512;
 constexpr int kEFloats = 4 * 2 * 32 * ETS;
@@ -129,9 +136,10 @@ struct KArgs {
     int N, C1, C2, H, W, Cout, padT, padL, act, tilesX, tilesY, nc1, nch;
 };
 
-template <int NT>
+template <int NT, int SQ>
 __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     constexpr int UFLOATS = ufloats_of(NT);
+    constexpr int TR = Geo<SQ>::TR, TC = Geo<SQ>::TC, RP = Geo<SQ>::RP, RPLANE = Geo<SQ>::RPLANE, LGTX = Geo<SQ>::LGTX;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Ub = smem;                  // 2 x UFLOATS
     float *Rb = smem + 2 * UFLOATS;    // 2 x RAWF
@@ -145,11 +153,11 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     const int grp = blockIdx.y;
     const long HW = (long)a.H * a.W;
 
-    // raw-tile DMA: lane q moves 16 bytes of plane q / 100, row (q % 100) / 10, column group q % 10
+    // raw-tile DMA: lane q moves 16 bytes of plane q / (RPLANE/4), row and column group from the remainder
     int voff = kXZero, dch = 4;
     if (tid < CK * RPLANE / 4) {
-        dch = tid / 100;
-        const int rem = tid % 100, r = rem / 10, c4 = rem % 10;
+        dch = tid / (RPLANE / 4);
+        const int rem = tid % (RPLANE / 4), r = rem / (RP / 4), c4 = rem % (RP / 4);
         const int gy = by * TR - a.padT + r, gx = bx * TC - 4 + 4 * c4;
         if (gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W) voff = (int)(((long)dch * a.H + gy) * a.W + gx) * 4;
     }
@@ -182,8 +190,11 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     // one VGPR base per operand stream and stage, kept opaque so that every other offset is an immediate of
     // ds_read2_b32 / ds_read2st64_b32 (no address arithmetic in the K loop)
     int rawA[2], rawB[2];
-    rawA[0] = lds_addr(Rb + lq * RPLANE + (4 * th + ra) * RP + (4 - a.padL) + 2 * l15);
-    rawB[0] = lds_addr(Rb + lq * RPLANE + (4 * th + rb) * RP + (4 - a.padL) + 2 * l15);
+    // tile 32 th + 16 mt + l15 -> tile row (tile >> LGTX), tile column (tile & (2^LGTX - 1))
+    const int trow0 = (32 * th + l15) >> LGTX, tcol0 = l15 & ((1 << LGTX) - 1);
+    constexpr int MTROWS = 16 >> LGTX;   // tile rows between the wave's two tile groups
+    rawA[0] = lds_addr(Rb + lq * RPLANE + (2 * trow0 + ra) * RP + (4 - a.padL) + 2 * tcol0);
+    rawB[0] = lds_addr(Rb + lq * RPLANE + (2 * trow0 + rb) * RP + (4 - a.padL) + 2 * tcol0);
     rawA[1] = rawA[0] + RAWF * 4;
     rawB[1] = rawB[0] + RAWF * 4;
     int bbase = lds_addr(Ub + (4 * pg) * NT * 64 + lane);
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
             float xv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                xv[j] = __builtin_fmaf(pb[mt * 2 * RP + j], sgn, pa[mt * 2 * RP + j]);
+                xv[j] = __builtin_fmaf(pb[mt * 2 * MTROWS * RP + j], sgn, pa[mt * 2 * MTROWS * RP + j]);
             av[mt][0] = xv[0] - xv[2];
             av[mt][1] = xv[1] + xv[2];
             av[mt][2] = xv[2] - xv[1];
@@ -247,8 +258,10 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
 
     // output transform.  E[pg][b][channel'][tile'] with tile' = lq + 4 r + 16 mt + 32 th; 32 channels a pass.
     float *E = smem;
-    const int rl_tx = lane & 15, rl_ty = lane >> 4;
-    const int tprime = (rl_tx >> 2) + 4 * (rl_tx & 3) + 16 * rl_ty;
+    // reader lane -> tile (row rl_ty, column rl_tx) = tile index T = (rl_ty << LGTX) + rl_tx; its slot is
+    // tile' = lq + 4 r + 16 (T >> 4) with 4 lq + r = T & 15
+    const int rl_tx = lane & ((1 << LGTX) - 1), rl_ty = lane >> LGTX;
+    const int tprime = ((lane & 15) >> 2) + 4 * (lane & 3) + 16 * (lane >> 4);
     const int oy = by * TR + 2 * rl_ty, ox = bx * TC + 2 * rl_tx;
     constexpr int PASSES = (NT + 1) / 2;
 #pragma unroll
@@ -535,6 +548,13 @@ bool wg_split(int C, int *g48, int *tail) {
 
 int nt_of(int Cout) { return Cout <= 48 ? 3 : 6; }
 
+// workgroup geometry for an H x W image: 0 = 8 x 32 pixels, 1 = 16 x 16 pixels, -1 = neither divides it
+int wino_square(int H, int W) {
+    if (H % Geo<0>::TR == 0 && W % Geo<0>::TC == 0) return 0;
+    if (H % Geo<1>::TR == 0 && W % Geo<1>::TC == 0) return 1;
+    return -1;
+}
+
 }  // namespace
 
 namespace sprk {
@@ -543,7 +563,10 @@ bool wino_eligible(const WinoGeom &g) {
     static const int on = getenv("SPRK_WINO") ? atoi(getenv("SPRK_WINO")) : 1;   // debug: 0 = direct kernels only
     if (!on) return false;
     if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.dil != 1 || g.up1 || g.up2 || g.res) return false;
-    if (g.Hout != g.H || g.Wout != g.W || g.H % TR || g.W % TC) return false;
+    if (g.Hout != g.H || g.Wout != g.W) return false;
+    const int sq = wino_square(g.H, g.W);
+    if (sq < 0) return false;
+    const int TR = sq ? Geo<1>::TR : Geo<0>::TR, TC = sq ? Geo<1>::TC : Geo<0>::TC;
     if (g.padL < 0 || g.padL > 4 || g.padT < 0) return false;
     if (g.C1 < 1 || g.C2 < 0 || g.Cout < 33) return false;
     const int NT = nt_of(g.Cout), groups = cdiv(g.Cout, NT * 16);
@@ -564,7 +587,8 @@ int wino_conv(const WinoArgs &w, hipStream_t s) {
     a.x = w.x; a.x2 = w.x2; a.U = w.U; a.bias = w.bias; a.scale = w.scale; a.shift = w.shift; a.y = w.y;
     a.N = w.N; a.C1 = w.C1; a.C2 = w.C2; a.H = w.H; a.W = w.W; a.Cout = w.Cout; a.padT = w.padT; a.padL = w.padL;
     a.act = w.act;
-    a.tilesX = w.W / TC; a.tilesY = w.H / TR;
+    const int sq = wino_square(w.H, w.W);
+    a.tilesX = w.W / (sq ? Geo<1>::TC : Geo<0>::TC); a.tilesY = w.H / (sq ? Geo<1>::TR : Geo<0>::TR);
     a.nc1 = cdiv(w.C1, CK);
     a.nch = a.nc1 + cdiv(w.C2, CK);
     if ((((uintptr_t)w.x | (uintptr_t)w.x2 | (uintptr_t)w.y | (uintptr_t)w.U) & 15) != 0) {
@@ -591,7 +615,9 @@ int wino_conv(const WinoArgs &w, hipStream_t s) {
         return (int)SPRK_OK;
     };
     prof_begin(w.kclass, w.flops, s);
-    if (int rc = NT == 6 ? launch(wino_conv_kernel<6>) : launch(wino_conv_kernel<3>)) return rc;
+    if (int rc = NT == 6 ? (sq ? launch(wino_conv_kernel<6, 1>) : launch(wino_conv_kernel<6, 0>))
+                         : (sq ? launch(wino_conv_kernel<3, 1>) : launch(wino_conv_kernel<3, 0>)))
+        return rc;
     prof_end(w.kclass, s);
     g_wino_launches.fetch_add(1, std::memory_order_relaxed);
     return SPRK_OK;

@@ -134,6 +134,8 @@ WINO_CASES = [
     ("wino shift 48->48 @64", 12, 48, 0, 64, 64, 48, (2, 0, 1, 1), 1, True, True, False),
     ("wino ragged 90->70 @8x96", 64, 90, 0, 8, 96, 70, (1, 1, 1, 1), 0, False, True, False),
     ("wino up-shift 41->96 @16x32 pad(0,2,2,0)", 96, 41, 0, 16, 32, 96, (0, 2, 2, 0), 2, True, True, False),
+    ("wino square tiles 96+48->96 @16x16", 192, 96, 48, 16, 16, 96, (2, 0, 1, 1), 1, True, True, False),
+    ("wino square tiles 48->48 @32x48", 32, 48, 0, 32, 48, 48, (1, 1, 1, 1), 2, True, True, False),
     ("wino+wgrad shift 96+1->96 @64", 128, 96, 1, 64, 64, 96, (2, 0, 1, 1), 1, True, False, True),
     ("wino+wgrad shift 96+48->96 @32x128", 128, 96, 48, 32, 128, 96, (2, 0, 1, 1), 1, True, True, True),
     ("wino+wgrad plain 48+10->88 @16x256 pad(1,1,2,0)", 130, 48, 10, 16, 256, 88, (1, 1, 2, 0), 0, True, False, True),
