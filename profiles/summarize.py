@@ -35,6 +35,9 @@ def family(name):
     m = re.match(r"(conv_mfma_kernel)<(\d+), (\d+),", name)
     if m:
         return "%s<%s, %s>" % m.groups()
+    m = re.match(r"(wino_conv_kernel)<(\d+),", name)   # <NT, tile geometry> -> <NT>
+    if m:
+        return "%s<%s>" % m.groups()
     m = re.match(r"(conv_wgrad_mfma_kernel)<", name)
     return m.group(1) if m else name
 
