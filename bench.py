@@ -154,7 +154,7 @@ def main():
     fence()
     L.sprk_prof_enable(0)
     warm = {kc: collect(kc) for kc in names}
-    DOM = max(names, key=lambda kc: warm[kc][1]) if args.warmup > 0 else 1
+    DOM = max(names, key=lambda kc: warm[kc][1]) if args.warmup > 0 else 3
     L.sprk_prof_enable(1 << DOM)   # events around the dominant kernel class only
     launches0 = L.sprk_launch_count()
     t0 = time.perf_counter()
