@@ -38,7 +38,7 @@ def nms_device(score, r, threshold, max_out=None):
         resume = 0
         while True:
             _lib.check(L.sprk_nms2d(_p(score), H, W, int(r), ctypes.c_float(thr), _p(out_s), _p(out_xy), _p(cnt), cap,
-                                    ROUNDS_PER_CALL, resume, _p(ws), nb, _stream()), "sprk_nms2d")
+                                    ROUNDS_PER_CALL, resume, _p(ws), nb, _stream(score)), "sprk_nms2d")
             n, undecided = cnt.tolist()
             if undecided == 0:
                 break

@@ -640,8 +640,11 @@ int wino_conv(const WinoArgs &w, hipStream_t s) {
     static const int persist = getenv("SPRK_WINO_PERSIST") ? atoi(getenv("SPRK_WINO_PERSIST")) : 1;
     const dim3 grid(persist ? std::min(a.ntiles, std::max(1, 256 / groups)) : a.ntiles, groups);
     const size_t lds = lds_bytes_of(NT);
+    // the four <NT, SQ> instantiations share one function-pointer type, hence one instance of this lambda: the
+    // "LDS opt-in done" flag is kept per instantiation explicitly
+    static bool attr_flags[2][2] = {{false, false}, {false, false}};
+    bool &attr_done = attr_flags[NT == 6 ? 1 : 0][sq ? 1 : 0];
     auto launch = [&](auto kernel) {
-        static bool attr_done = false;   // per instantiation
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds) != hipSuccess) {

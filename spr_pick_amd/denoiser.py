@@ -82,6 +82,8 @@ class Denoiser(nn.Module):
         if self.device.type != "cuda":
             raise RuntimeError("spr_pick_amd.Denoiser runs on the GPU only (device=%s); use the oracle/ "
                                "restatement for CPU checks" % self.device)
+        if self.device.index is not None and self.device.index != torch.cuda.current_device():
+            torch.cuda.set_device(self.device)   # one process drives one GPU: its kernels go to THIS card's streams
         self.cfg = cfg
         self.mode = mode
         self.models = nn.ModuleDict()

@@ -12,8 +12,16 @@ from . import _lib
 from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ConvEpilogue, ConvGeom, check  # noqa: F401
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(t):
+    """torch's current stream on the device that holds ``t`` (a kernel must be enqueued on a stream of the
+    device its pointers live on).  One process drives one GPU here; a tensor on another device than the
+    process's current one is a set-up error and raises instead of launching on the wrong card."""
+    dev = t.device
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        raise _lib.SprkError("tensor on %s but the current device is cuda:%d — call torch.cuda.set_device(%d) "
+                             "(Denoiser / DenoiserTrainer / DenoiserEvaluator do it for their own device)"
+                             % (dev, torch.cuda.current_device(), dev.index))
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def _p(t):
@@ -67,7 +75,7 @@ def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None,
                       1 if up_out else 0)
     nb = L.sprk_conv2d_fwd_ws_bytes(ctypes.byref(g))
     ws = _ws(nb, x)
-    check(L.sprk_conv2d_fwd(_p(x), _p(x2), _p(w), _p(y), ctypes.byref(g), ctypes.byref(ep), _p(ws), nb, _stream()),
+    check(L.sprk_conv2d_fwd(_p(x), _p(x2), _p(w), _p(y), ctypes.byref(g), ctypes.byref(ep), _p(ws), nb, _stream(x)),
           "sprk_conv2d_fwd")
     return y
 
@@ -108,14 +116,14 @@ class _Conv2dFn(torch.autograd.Function):
             nb = L.sprk_act_bwd_ws_bytes(g.N, g.Cout, g.Hout * g.Wout)
             ws = _ws(nb, gy)
             check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre) if gpre is not gy else None, _p(gb), ctx.act,
-                                 g.N, g.Cout, g.Hout, g.Wout, up2, _p(ws), nb, _stream()), "sprk_act_bwd")
+                                 g.N, g.Cout, g.Hout, g.Wout, up2, _p(ws), nb, _stream(gy)), "sprk_act_bwd")
         else:
             gpre = gy
         if ctx.needs_input_grad[2]:
             gw = torch.empty_like(w)
             nb = L.sprk_conv2d_bwd_weight_ws_bytes(ctypes.byref(g))
             ws = _ws(nb, gy)
-            check(L.sprk_conv2d_bwd_weight(_p(x), _p(x2), _p(gpre), _p(gw), ctypes.byref(g), _p(ws), nb, _stream()),
+            check(L.sprk_conv2d_bwd_weight(_p(x), _p(x2), _p(gpre), _p(gw), ctypes.byref(g), _p(ws), nb, _stream(x)),
                   "sprk_conv2d_bwd_weight")
         need0 = ctx.needs_input_grad[0]
         need1 = x2 is not None and ctx.needs_input_grad[1]
@@ -130,7 +138,7 @@ class _Conv2dFn(torch.autograd.Function):
             gin = torch.empty((gd.N, gd.C1 + gd.C2, gd.Hin, gd.Win), dtype=torch.float32, device=gy.device)
             nb = L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(gd))
             ws = _ws(nb, gy)
-            check(L.sprk_conv2d_bwd_data(_p(gpre), _p(wd), _p(gin), ctypes.byref(gd), _p(ws), nb, _stream()),
+            check(L.sprk_conv2d_bwd_data(_p(gpre), _p(wd), _p(gin), ctypes.byref(gd), _p(ws), nb, _stream(gpre)),
                   "sprk_conv2d_bwd_data")
             if gd.C2 == 0 and not gd.up1:
                 gx = gin
@@ -138,7 +146,7 @@ class _Conv2dFn(torch.autograd.Function):
                 gx = torch.empty_like(x)
                 gx2 = torch.empty_like(x2) if gd.C2 else None
                 check(L.sprk_concat_up_bwd(_p(gin), _p(gx), _p(gx2), gd.N, gd.C1, gd.C2, gd.Hin, gd.Win, gd.up1,
-                                           _stream()), "sprk_concat_up_bwd")
+                                           _stream(gin)), "sprk_concat_up_bwd")
         return gx, gx2, gw, gb, None, None, None, None, None, None
 
 
@@ -160,7 +168,7 @@ class _ShiftMaxPoolFn(torch.autograd.Function):
         if H % 2 or W % 2:
             raise ValueError("shift_maxpool2: odd spatial size %dx%d" % (H, W))
         y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
-        check(_lib.lib().sprk_shift_maxpool2_fwd(_p(x), _p(y), N * C, H, W, shift, _stream()), "sprk_shift_maxpool2_fwd")
+        check(_lib.lib().sprk_shift_maxpool2_fwd(_p(x), _p(y), N * C, H, W, shift, _stream(x)), "sprk_shift_maxpool2_fwd")
         ctx.shift = shift
         ctx.save_for_backward(x)
         return y
@@ -171,7 +179,7 @@ class _ShiftMaxPoolFn(torch.autograd.Function):
         gy = gy.contiguous()
         N, C, H, W = x.shape
         gx = torch.empty_like(x)
-        check(_lib.lib().sprk_shift_maxpool2_bwd(_p(gy), _p(x), _p(gx), N * C, H, W, ctx.shift, _stream()),
+        check(_lib.lib().sprk_shift_maxpool2_bwd(_p(gy), _p(x), _p(gx), N * C, H, W, ctx.shift, _stream(gy)),
               "sprk_shift_maxpool2_bwd")
         return gx, None
 
@@ -189,7 +197,7 @@ class _Rot4Fn(torch.autograd.Function):
         if H != W:
             raise ValueError("rot4_stack needs square images, got %dx%d" % (H, W))
         y = torch.empty((4 * B, C, H, W), dtype=x.dtype, device=x.device)
-        check(_lib.lib().sprk_rot4_stack_fwd(_p(x), _p(y), B, C, H, _stream()), "sprk_rot4_stack_fwd")
+        check(_lib.lib().sprk_rot4_stack_fwd(_p(x), _p(y), B, C, H, _stream(x)), "sprk_rot4_stack_fwd")
         return y
 
     @staticmethod
@@ -197,7 +205,7 @@ class _Rot4Fn(torch.autograd.Function):
         gy = gy.contiguous()
         B4, C, P, _ = gy.shape
         gx = torch.empty((B4 // 4, C, P, P), dtype=gy.dtype, device=gy.device)
-        check(_lib.lib().sprk_rot4_stack_bwd(_p(gy), _p(gx), B4 // 4, C, P, _stream()), "sprk_rot4_stack_bwd")
+        check(_lib.lib().sprk_rot4_stack_bwd(_p(gy), _p(gx), B4 // 4, C, P, _stream(gy)), "sprk_rot4_stack_bwd")
         return gx
 
 
@@ -214,7 +222,7 @@ class _UnrotFn(torch.autograd.Function):
         if P != W or B4 % 4:
             raise ValueError("unrot4_shift_concat: bad shape %s" % (tuple(d.shape),))
         f = torch.empty((B4 // 4, 4 * C, P, P), dtype=d.dtype, device=d.device)
-        check(_lib.lib().sprk_unrot4_shift_concat_fwd(_p(d), _p(f), B4 // 4, C, P, _stream()), "sprk_unrot4_fwd")
+        check(_lib.lib().sprk_unrot4_shift_concat_fwd(_p(d), _p(f), B4 // 4, C, P, _stream(d)), "sprk_unrot4_fwd")
         return f
 
     @staticmethod
@@ -222,7 +230,7 @@ class _UnrotFn(torch.autograd.Function):
         gf = gf.contiguous()
         B, C4, P, _ = gf.shape
         gd = torch.empty((4 * B, C4 // 4, P, P), dtype=gf.dtype, device=gf.device)
-        check(_lib.lib().sprk_unrot4_shift_concat_bwd(_p(gf), _p(gd), B, C4 // 4, P, _stream()), "sprk_unrot4_bwd")
+        check(_lib.lib().sprk_unrot4_shift_concat_bwd(_p(gf), _p(gd), B, C4 // 4, P, _stream(gf)), "sprk_unrot4_bwd")
         return gd
 
 
@@ -255,7 +263,7 @@ class _BNTrainFn(torch.autograd.Function):
             sl = slice(g * Ng, (g + 1) * Ng)
             check(L.sprk_bn_train_fwd(_p(x[sl]), _p(y[sl]), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                                       _p(mean[g]), _p(invstd[g]), Ng, C, H * W, momentum, eps, int(relu), _p(ws), nb,
-                                      _stream()), "sprk_bn_train_fwd")
+                                      _stream(x)), "sprk_bn_train_fwd")
         ctx.relu, ctx.groups = relu, groups
         ctx.save_for_backward(x, y, gamma, mean, invstd)
         return y
@@ -277,7 +285,7 @@ class _BNTrainFn(torch.autograd.Function):
             sl = slice(g * Ng, (g + 1) * Ng)
             check(L.sprk_bn_train_bwd(_p(gy[sl]), _p(x[sl]), _p(y[sl]), _p(gamma), _p(mean[g]), _p(invstd[g]),
                                       _p(gx[sl]), _p(gg[g]), _p(gb[g]), Ng, C, H * W, int(ctx.relu), _p(ws), nb,
-                                      _stream()), "sprk_bn_train_bwd")
+                                      _stream(gy)), "sprk_bn_train_bwd")
         if groups > 1:
             gg, gb = gg.sum(0), gb.sum(0)
         else:
@@ -297,7 +305,7 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, relu=Fa
     N, C, H, W = x.shape
     y = torch.empty_like(x)
     check(_lib.lib().sprk_bn_eval_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                      N, C, H * W, float(eps), int(relu), _stream()), "sprk_bn_eval_fwd")
+                                      N, C, H * W, float(eps), int(relu), _stream(x)), "sprk_bn_eval_fwd")
     return y
 
 
@@ -312,7 +320,7 @@ class _ReparamFn(torch.autograd.Function):
         if C != 2:
             raise ValueError("reparameterize expects out_stats with 2 channels")
         z = torch.empty((B, 1, H, W), dtype=out_stats.dtype, device=out_stats.device)
-        check(_lib.lib().sprk_reparam_fwd(_p(out_stats), _p(eps), _p(z), B, H * W, _stream()), "sprk_reparam_fwd")
+        check(_lib.lib().sprk_reparam_fwd(_p(out_stats), _p(eps), _p(z), B, H * W, _stream(out_stats)), "sprk_reparam_fwd")
         ctx.save_for_backward(out_stats, eps)
         return z
 
@@ -322,7 +330,7 @@ class _ReparamFn(torch.autograd.Function):
         gz = gz.contiguous()
         B, _, H, W = out_stats.shape
         go = torch.empty_like(out_stats)
-        check(_lib.lib().sprk_reparam_bwd(_p(gz), _p(out_stats), _p(eps), _p(go), B, H * W, _stream()), "sprk_reparam_bwd")
+        check(_lib.lib().sprk_reparam_bwd(_p(gz), _p(out_stats), _p(eps), _p(go), B, H * W, _stream(gz)), "sprk_reparam_bwd")
         return go, None
 
 
@@ -336,7 +344,7 @@ class _SigmoidClampFn(torch.autograd.Function):
         x = x.contiguous()
         _need_gpu(x)
         p = torch.empty_like(x)
-        check(_lib.lib().sprk_sigmoid_clamp_fwd(_p(x), _p(p), x.numel(), _stream()), "sprk_sigmoid_clamp_fwd")
+        check(_lib.lib().sprk_sigmoid_clamp_fwd(_p(x), _p(p), x.numel(), _stream(x)), "sprk_sigmoid_clamp_fwd")
         ctx.save_for_backward(x)
         return p
 
@@ -345,7 +353,7 @@ class _SigmoidClampFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         gp = gp.contiguous()
         gx = torch.empty_like(x)
-        check(_lib.lib().sprk_sigmoid_clamp_bwd(_p(gp), _p(x), _p(gx), x.numel(), _stream()), "sprk_sigmoid_clamp_bwd")
+        check(_lib.lib().sprk_sigmoid_clamp_bwd(_p(gp), _p(x), _p(gx), x.numel(), _stream(gp)), "sprk_sigmoid_clamp_bwd")
         return gx
 
 
@@ -367,7 +375,7 @@ class _SsdnFn(torch.autograd.Function):
         mstd = torch.empty((1, B, H, W), dtype=torch.float32, device=x.device)
         nb = L.sprk_ssdn_ws_bytes(B, H * W)
         ws = _ws(nb, x)
-        check(L.sprk_ssdn_fwd(_p(x), _p(out_stats), _p(ns), _p(loss), _p(pme), _p(mstd), B, H * W, _p(ws), nb, _stream()),
+        check(L.sprk_ssdn_fwd(_p(x), _p(out_stats), _p(ns), _p(loss), _p(pme), _p(mstd), B, H * W, _p(ws), nb, _stream(x)),
               "sprk_ssdn_fwd")
         ctx.save_for_backward(x, out_stats, ns)
         ctx.ns_shape = noise_std.shape
@@ -384,7 +392,7 @@ class _SsdnFn(torch.autograd.Function):
         gns = torch.empty(B, dtype=torch.float32, device=x.device)
         nb = L.sprk_ssdn_ws_bytes(B, H * W)
         ws = _ws(nb, x)
-        check(L.sprk_ssdn_bwd(_p(gl), _p(x), _p(out_stats), _p(ns), _p(go), _p(gns), B, H * W, _p(ws), nb, _stream()),
+        check(L.sprk_ssdn_bwd(_p(gl), _p(x), _p(out_stats), _p(ns), _p(go), _p(gns), B, H * W, _p(ws), nb, _stream(gl)),
               "sprk_ssdn_bwd")
         return None, go, gns.reshape(ctx.ns_shape)
 

@@ -77,6 +77,8 @@ class DenoiserTrainer:
         self.seed = seed
         self.rank, self.world, local = distributed.init_from_env()
         self.device = torch.device(device) if device else torch.device("cuda", local)
+        if self.device.type == "cuda" and torch.cuda.is_available():
+            torch.cuda.set_device(self.device)      # one process drives one GPU (kernels go to ITS streams)
         self._denoiser = None
         self._optimizer = None
         self._grad_sync = None
@@ -104,6 +106,17 @@ class DenoiserTrainer:
         torch.manual_seed(self.seed)            # same initial weights on every rank
         self.denoiser = Denoiser(self.cfg, device=self.device, mode=self.mode)
         self.init_state()
+        self.seed_streams()
+
+    def seed_streams(self):
+        """Per-rank random streams for everything drawn AFTER the (identical) initial weights: the
+        reparameterisation noise on the device and the flip-axis draw of the pipeline (global NumPy state).
+        On resume the streams are keyed by the sample counter too, so a resumed run does not replay the
+        draws (and, through PatchFeed's seed, the patches) of its first segment."""
+        it = int(self.state.get(StateValue.ITERATION, 0) or 0)
+        s = (self.seed + 1000 + self.rank + 7919 * it) % (2 ** 31 - 1)
+        torch.manual_seed(s)
+        np.random.seed(s)
 
     def init_state(self):
         self.state[StateValue.INITIALISED] = True
@@ -329,6 +342,7 @@ class DenoiserTrainer:
             except ValueError as e:
                 logger.warning("optimizer state not restored: %s", e)
         torch.set_rng_state(state_dict["rng"])
+        self.seed_streams()       # device + NumPy streams (and the patch sampler below) continue, not replay
 
     # ---- metrics / logging ---------------------------------------------------------------------
     def reset_metrics(self, eval=True, train=True):
@@ -462,7 +476,8 @@ class DenoiserTrainer:
         if batch % self.world:
             raise ValueError("train batch size %d is not divisible by the %d ranks" % (batch, self.world))
         return feed_mod.PatchFeed(groups, names, batch // self.world, patch=c[ConfigValue.TRAIN_PATCH_SIZE],
-                                  device=self.device, balance=0.1, seed=self.seed + self.rank,
+                                  device=self.device, balance=0.1,
+                                  seed=self.seed + self.rank + 7919 * int(self.state.get(StateValue.ITERATION, 0) or 0),
                                   size=c[ConfigValue.ITERATIONS] * batch)
 
     def test_data(self):

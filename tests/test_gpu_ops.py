@@ -1,5 +1,7 @@
 """GPU parity of every libsprk.so operator against a plain PyTorch fp32/fp64 CPU statement of the
 same op (floating-point kernels: tolerance stated per test), through the C ABI."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -83,7 +85,7 @@ CONV_CASES = [
 def test_conv2d_fwd_bwd(case, naive):
     from spr_pick_amd import _lib, ops
     name, N, C1, C2, H, W, up1, Cout, K, stride, dil, pad, act, has_b = case
-    g = torch.Generator().manual_seed(abs(hash(name)) % 10000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
     h1, w1 = (H // 2, W // 2) if up1 else (H, W)
     x = torch.randn(N, C1, h1, w1, generator=g)
     x2 = torch.randn(N, C2, H, W, generator=g) if C2 else None
@@ -149,7 +151,7 @@ def test_conv2d_winograd(case):
     roundings per product, far inside 2e-5 of the tensor scale), plus proof that the Winograd kernel ran."""
     from spr_pick_amd import _lib, ops
     name, N, C1, C2, H, W, Cout, pad, act, has_b, bwd_wino, wg_wino = case
-    g = torch.Generator().manual_seed(abs(hash(name)) % 10000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
     x = torch.randn(N, C1, H, W, generator=g)
     x2 = torch.randn(N, C2, H, W, generator=g) if C2 else None
     w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / np.sqrt((C1 + C2) * 9)
