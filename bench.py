@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: joint denoise+detect TRAINING throughput (patches/s) on synthetic
-1024x1024 micrographs, 64x64 patches (BASELINE.json configs[1]: ssdn/gaussian, batch 32 per GPU).
+1024x1024 micrographs, 64x64 patches (BASELINE.json configs[1]: ssdn/gaussian, batch 32 per GPU),
+plus the inference legs (filled whole-micrograph forward + NMS, Mpix/s; configs[2] is the 4096^2 one).
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
@@ -10,6 +11,9 @@ One step = zero_grad -> Denoiser.run_pipeline(train) (2 JointNetwork passes + si
 timed region.  Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
 """
 import argparse
+import ctypes
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -24,6 +28,26 @@ sys.path.insert(0, ROOT)
 FLOP_PER_PATCH_STEP = 67.90e9       # 33.95 GMAC fwd+bwd per patch
 FLOP_PER_INFER_PIXEL = 3.4756e6
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s achievable)
+WINOGRAD_GAIN = 2.25                # F(2x2,3x3): 16 multiplies per 2x2 output tile and channel pair instead of 36
+
+# kernel classes of include/sprk.h (sprk_prof_*).  `bound` = the algorithmic-FLOP rate the kernel's OWN algorithm
+# allows on the fp32 matrix pipes: a direct convolution issues every algorithmic FLOP as an MFMA FLOP (157.3 TF);
+# a Winograd F(2x2,3x3) kernel issues 4/9 of them, so 2.25 x 157.3 TF of algorithmic FLOPs saturate the pipes.
+KCLASS = {
+    0: ("conv_mfma_kernel<4, 6>", 1.0,
+        "direct implicit-GEMM forward / backward-data, all <MT=4, NT=6, row bases, staging> instantiations"),
+    1: ("conv_wgrad_mfma_kernel", 1.0, "direct backward-weight, all instantiations"),
+    2: ("conv_mfma_kernel<other> + wino_conv_kernel<3>", 1.0,
+        "the narrow / small direct instantiations and the 48-channel Winograd kernel (priced as direct)"),
+    3: ("wino_conv_kernel<6>", WINOGRAD_GAIN,
+        "Winograd F(2x2,3x3) forward / backward-data of the 96-channel 3x3 layers. achieved = algorithmic FLOPs of the "
+        "convolution (2*N*H*W*Cout*Cin*9, SURVEY 8d) / launch time; the kernel issues 4/9 of them as MFMA FLOPs, so "
+        "peak = 2.25 x 157.3 TF and frac = the busy fraction of the fp32 matrix pipes"),
+    4: ("wino_wgrad_kernel", WINOGRAD_GAIN,
+        "Winograd F(2x2,3x3) backward-weight of the largest layers (main and tail-channel launches); issues 4/9 of "
+        "the algorithmic FLOPs as MFMA FLOPs"),
+}
 
 
 def make_cfg():
@@ -37,14 +61,28 @@ def make_cfg():
     return cfg.infer(c, model_only=True)
 
 
+def kernel_source_hash():
+    """Identity of the kernels a committed PMC profile belongs to: SHA-1 over the HIP sources."""
+    h = hashlib.sha1()
+    for p in sorted(glob.glob(os.path.join(ROOT, "spr_pick_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "spr_pick_amd", "csrc", "*.h"))):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def cpu_threads():
+    # host cores this process may actually use (the GPU box exposes 256 logical CPUs but grants a share of
+    # them; oversubscribing torch's intra-op pool makes the CPU path orders slower).  SPRK_CPU_THREADS overrides.
+    return min(len(os.sched_getaffinity(0)), int(os.environ.get("SPRK_CPU_THREADS", "16")))
+
+
 def cpu_baseline(micrographs, seconds):
     """The oracle (CPU restatement of the reference path) timed on the host cores, BASELINE
     configs[0]: batch 4, same synthetic patches; a bounded sample of ~`seconds` of CPU work."""
     from oracle import pipeline, weights
     from spr_pick_amd import synthetic
-    # host cores this process may actually use (the GPU box exposes 256 logical CPUs but grants a
-    # share of them; oversubscribing torch's intra-op pool makes the CPU path orders slower)
-    threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("SPRK_CPU_THREADS", "16")))
+    threads = cpu_threads()
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     sd = weights.make_state(weights.denoiser_shapes(), seed=0)
@@ -79,18 +117,99 @@ def cpu_baseline(micrographs, seconds):
                       "oracle/ restatement on torch CPU" % (n, dt)}
 
 
+def cpu_inference_baseline(size):
+    """one filled eval forward + NMS of a `size`^2 synthetic micrograph on the host cores
+    (oracle/ restatement: torch CPU networks + the C greedy NMS)."""
+    from oracle import nms, pipeline, weights
+    from spr_pick_amd import synthetic
+    threads = cpu_threads()
+    torch.set_num_threads(threads)
+    sd = weights.make_state(weights.denoiser_shapes(), seed=0)
+    img = torch.from_numpy(synthetic.micrograph(7, size=size)[0].astype(np.float32) / 255.0)[None, None]
+    eps = torch.randn(img.shape, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        res = pipeline.joint_pipeline(sd, img, None, 0, 0, False, eps)
+        t1 = time.perf_counter()
+        s, _ = nms.nms_c(res["DETECT"][0, 0].numpy(), 18, 0.02)
+        t2 = time.perf_counter()
+    return {"value": size * size / (t2 - t0) / 1e6, "unit": "Mpix/s", "cores": threads, "kind": "port",
+            "sample": "one %dx%d filled eval forward (%.1f s) + C greedy NMS r=18 thr=0.02 (%.3f s, %d picks); oracle/ "
+                      "restatement on torch CPU" % (size, size, t1 - t0, t2 - t1, len(s))}
+
+
+def inference_leg(den, dev, size, reps):
+    """Whole-micrograph filled inference as the evaluator runs it (reference train.py:383-415,557-571): host
+    uint8 micrograph -> H2D -> /255 -> JointNetwork filled + sigma net + posterior mean + clamped sigmoid -> NMS
+    (r=18, thr 0.02) -> picks back on the host.  H2D and the D2H of the picks are inside the timed region."""
+    from spr_pick_amd import DetectionDataset, nms_device, synthetic
+    from spr_pick_amd.params import PipelineOutput as P
+    host_u8 = torch.from_numpy(synthetic.micrograph(7, size=size)[0]).pin_memory()
+    zeros = torch.zeros(1, 1)
+    den.eval(); den.fill()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    t_net = t_nms = t_h2d = 0.0
+    try:
+        with torch.no_grad():
+            def once(timed):
+                nonlocal t_net, t_nms, t_h2d
+                ev[0].record()
+                img = host_u8.to(dev, non_blocking=True).to(torch.float32).div_(255.0)[None, None]
+                ev[1].record()
+                oe = den.run_pipeline(DetectionDataset.make_batch(img, zeros), train=False)
+                score = oe[P.DETECT][0, 0]
+                ev[2].record()
+                s, c = nms_device(score, 18, 0.02)
+                s, c = s.cpu(), c.cpu()
+                ev[3].record()
+                torch.cuda.synchronize()
+                if timed:
+                    t_h2d += ev[0].elapsed_time(ev[1]); t_net += ev[1].elapsed_time(ev[2]); t_nms += ev[2].elapsed_time(ev[3])
+                return len(s)
+            once(False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                n_picks = once(True)
+            dt = (time.perf_counter() - t0) / reps
+    finally:
+        den.unfill(); den.train()
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 1e9
+    torch.cuda.empty_cache()
+    nms_ms = t_nms / reps
+    nms_bytes = 4.0 * size * size + 12.0 * n_picks      # SURVEY.md §8d: read every score once, write the picks
+    return {"metric": "inference_mpix_per_sec", "value": size * size / dt / 1e6, "unit": "Mpix/s", "size": [size, size],
+            "reps": reps, "ms_per_micrograph": dt * 1e3, "h2d_ms": t_h2d / reps, "network_ms": t_net / reps,
+            "includes": "H2D of the uint8 micrograph, network, NMS, D2H of the picks", "picks": int(n_picks),
+            "peak_hbm_gb": peak_gb,
+            "mfma_frac_direct": size * size / dt * FLOP_PER_INFER_PIXEL / (PEAK_FP32_MFMA_TFLOPS * 1e12),
+            "nms": {"ms": nms_ms, "radius": 18, "threshold": 0.02, "bytes": nms_bytes,
+                    "achieved_gbs": nms_bytes / (nms_ms * 1e-3) / 1e9 if nms_ms > 0 else 0.0,
+                    "frac_of_hbm": nms_bytes / (nms_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if nms_ms > 0 else 0.0,
+                    "picks_per_s": n_picks / (nms_ms * 1e-3) if nms_ms > 0 else 0.0,
+                    "note": "algorithmic bytes 4*H*W + 12*n_picks; the greedy dependency chain, not bandwidth, bounds it "
+                            "(includes the D2H of the picks)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="patches per GPU per step (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="fixed global batch split over the GPUs (strong scaling; 128 = BASELINE configs[3])")
+    ap.add_argument("--graph", choices=("on", "off"), default="on",
+                    help="replay the forward+backward from HIP graphs (on) or enqueue every launch from Python (off)")
+    ap.add_argument("--event-steps", type=int, default=10,
+                    help="eager steps after the timed region whose dominant-kernel launches are bracketed by HIP events")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--infer-size", type=int, default=1024, help="side of the inference micrograph (0 = skip)")
+    ap.add_argument("--infer-size", type=int, default=1024, help="side of the small inference micrograph (0 = skip)")
+    ap.add_argument("--infer-large", type=int, default=4096, help="side of the configs[2] micrograph (0 = skip)")
     args = ap.parse_args()
 
-    from spr_pick_amd import Denoiser, DetectionDataset, _lib, distributed, nms_device, synthetic
+    from spr_pick_amd import Denoiser, _lib, distributed, graph_step, synthetic
     from spr_pick_amd.params import PipelineOutput as P
     import torch.distributed as dist
 
@@ -100,25 +219,30 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     L = _lib.lib()
+    if args.global_batch:
+        assert args.global_batch % world == 0, "--global-batch must divide over the GPUs"
+        batch, scaling = args.global_batch // world, "strong"
+    else:
+        batch, scaling = args.batch, "weak"
 
     mics = [synthetic.micrograph(i) for i in range(4)]
     torch.manual_seed(0)
     den = Denoiser(make_cfg(), device=dev, mode="joint")
     den.train()
     params = [p for p in den.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=1e-4, betas=(0.9, 0.99))
-    sync = distributed.FlatGradAllReduce(params, world)
+    opt = graph_step.make_adam(params, lr=1e-4, betas=(0.9, 0.99))
+    use_graph = args.graph != "off"
+    stepper = graph_step.GraphedTrainStep(den, batch, 64, 0.75, 0.01, world=world, graph=use_graph)
     nb = min(16, args.steps + args.warmup)
-    batches = synthetic.patch_batches(nb, args.batch, mics, seed=100 + rank, device=dev)
+    batches = synthetic.patch_batches(nb, batch, mics, seed=100 + rank, device=dev)
     np.random.seed(1000 + rank)
     torch.manual_seed(1000 + rank)
 
-    def step(i):
+    def step(i, eager=False):
+        """forward + backward (HIP-graph replay unless `eager`) -> in-place flat gradient all-reduce -> fused Adam"""
         inp, tgt = batches[i % nb]
-        opt.zero_grad(set_to_none=True)
-        o = den.run_pipeline(DetectionDataset.make_batch(inp, tgt), 0.75, 0.01, train=True)
-        torch.mean(o[P.LOSS]).backward()
-        sync()
+        o = stepper(inp, tgt, eager=eager)
+        stepper.grads.all_reduce(world)
         opt.step()
         return o
 
@@ -127,39 +251,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    import ctypes
-
     def collect(kc):
         n_, ms_, fl_ = ctypes.c_long(), ctypes.c_double(), ctypes.c_double()
         L.sprk_prof_collect(kc, ctypes.byref(n_), ctypes.byref(ms_), ctypes.byref(fl_))
         return n_.value, ms_.value, fl_.value
 
-    # kernel classes of include/sprk.h; the roofline leg goes to the class that takes the most GPU time in the
-    # warm-up steps (all classes bracketed there; an event pair is not free, so the timed region brackets one)
-    names = {0: "conv_mfma_kernel<4, 6>", 1: "conv_wgrad_mfma_kernel", 2: "conv_mfma_kernel<other> + wino_conv_kernel<3>",
-             3: "wino_conv_kernel<6>", 4: "wino_wgrad_kernel"}
-    notes = {
-        0: "direct implicit-GEMM forward / backward-data, all <MT=4, NT=6, row bases, staging> instantiations",
-        1: "direct backward-weight, all instantiations",
-        2: "the narrow / small direct instantiations and the 48-channel Winograd kernel",
-        3: "Winograd F(2x2,3x3) forward / backward-data of the 96-channel 3x3 layers. achieved = algorithmic FLOPs of "
-           "the convolution (2*N*H*W*Cout*Cin*9, SURVEY 8d) / launch time; the kernel issues 4/9 of them as MFMA "
-           "FLOPs (mfma_pipe_frac = achieved * 4/9 / peak)",
-        4: "Winograd F(2x2,3x3) backward-weight of the largest layers (main and tail-channel launches); issues 4/9 "
-           "of the algorithmic FLOPs as MFMA FLOPs",
-    }
+    # Kernel timing by HIP events (sprk_prof_*) needs eager launches: events cannot bracket the nodes of a replayed
+    # graph.  (1) two eager steps with every MFMA class bracketed pick the class with the most GPU time; (2) the
+    # timed region replays the graphs (that is `value`); (3) right after it `--event-steps` eager steps of the SAME
+    # kernels on the same batches are bracketed for the dominant class (the roofline leg) and three more for the
+    # others.  With --graph off the timed region itself is bracketed, as in round 1.
     L.sprk_prof_enable(31)
+    for i in range(2):
+        step(i, eager=True)
+    fence()
+    L.sprk_prof_enable(0)
+    warm = {kc: collect(kc) for kc in KCLASS}
+    DOM = max(KCLASS, key=lambda kc: warm[kc][1])
+    stepper.prepare(*batches[0])     # captures both flip-axis graphs (no-op with --graph off)
     for i in range(args.warmup):
         step(i)
     fence()
-    L.sprk_prof_enable(0)
-    warm = {kc: collect(kc) for kc in names}
-    DOM = max(names, key=lambda kc: warm[kc][1]) if args.warmup > 0 else 3
-    L.sprk_prof_enable(1 << DOM)   # events around the dominant kernel class only
+    if not use_graph:
+        L.sprk_prof_enable(1 << DOM)
     launches0 = L.sprk_launch_count()
     t0 = time.perf_counter()
     for i in range(args.steps):
         o = step(args.warmup + i)
+    t_enq = time.perf_counter() - t0          # host time to enqueue all steps (before the device has drained)
     fence()
     dt = time.perf_counter() - t0
     L.sprk_prof_enable(0)
@@ -170,84 +289,112 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    prof = {DOM: (names[DOM],) + collect(DOM)}
-    # the other MFMA kernels: three more steps after the timed region, every class bracketed
+    if use_graph:
+        L.sprk_prof_enable(1 << DOM)
+        for i in range(args.event_steps):
+            step(args.warmup + args.steps + i, eager=True)
+        fence()
+        L.sprk_prof_enable(0)
+    prof = {DOM: collect(DOM)}
+    # the other MFMA kernels: three more eager steps, every class bracketed
     L.sprk_prof_enable(31)
     for i in range(3):
-        step(args.warmup + args.steps + i)
+        step(args.warmup + args.steps + i, eager=True)
     fence()
     L.sprk_prof_enable(0)
     extra_dom = collect(DOM)
-    others = tuple(k for k in names if k != DOM)
+    others = tuple(k for k in KCLASS if k != DOM)
     for kc in others:
-        prof[kc] = (names[kc],) + collect(kc)
-    all_ms = extra_dom[1] + sum(prof[k][2] for k in others)
-    all_fl = extra_dom[2] + sum(prof[k][3] for k in others)
+        prof[kc] = collect(kc)
+    all_ms = extra_dom[1] + sum(prof[k][1] for k in others)
+    all_fl = extra_dom[2] + sum(prof[k][2] for k in others)
 
-    infer = None
-    if args.infer_size and rank == 0:
-        S = args.infer_size
-        img = torch.from_numpy(synthetic.micrograph(7, size=S)[0].astype(np.float32) / 255.0).to(dev)[None, None]
-        den.eval(); den.fill()
-        with torch.no_grad():
-            def infer_once():
-                oe = den.run_pipeline(DetectionDataset.make_batch(img, torch.zeros(1, 1)), train=False)
-                return nms_device(oe[P.DETECT][0, 0], 18, 0.02)
-            infer_once()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            reps = 3
-            for _ in range(reps):
-                s_, c_ = infer_once()
-            torch.cuda.synchronize()
-            ti = (time.perf_counter() - t1) / reps
-        den.unfill(); den.train()
-        infer = {"metric": "inference_mpix_per_sec", "value": S * S / ti / 1e6, "unit": "Mpix/s", "size": [S, S],
-                 "ms_per_micrograph": ti * 1e3, "picks": int(len(s_)), "nms_radius": 18,
-                 "mfma_frac": S * S / ti * FLOP_PER_INFER_PIXEL / (PEAK_FP32_MFMA_TFLOPS * 1e12)}
+    infer = infer_large = None
+    if rank == 0:
+        del o
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+        if args.infer_size:
+            infer = inference_leg(den, dev, args.infer_size, reps=5)
+        if args.infer_large:
+            torch.cuda.reset_peak_memory_stats(dev)
+            infer_large = inference_leg(den, dev, args.infer_large, reps=3)
+            infer_large["workload"] = "BASELINE configs[2]: one of the 128 synthetic 4096x4096 micrographs per repetition"
 
     if rank != 0:
         return
-    patches = world * args.batch * args.steps
+    patches = world * batch * args.steps
     value = patches / dt
-    nm, n0, ms0, fl0 = prof[DOM]
+    nm, gain, note = KCLASS[DOM]
+    n0, ms0, fl0 = prof[DOM]
     achieved = fl0 / (ms0 * 1e-3) / 1e12 if ms0 > 0 else 0.0
-    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read in-process; they are
-    # collected with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) on
-    # this same command and committed under profiles/ 
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            traffic = json.load(f)["kernels"][nm]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    peak = PEAK_FP32_MFMA_TFLOPS * gain
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read in-process.  They are collected with
+    # rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) on this same command by
+    # profiles/collect.sh; the committed summary is used ONLY when it was taken from the kernel sources in this tree.
+    traffic, traffic_src = None, "not measured in this run (PMC counters need rocprofv3: profiles/collect.sh)"
+    khash = kernel_source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                tj = json.load(f)
+            if tj.get("kernel_source_hash") == khash:
+                traffic = tj["kernels"][nm]["hbm_bytes_per_launch"]
+                traffic_src = "%s: rocprofv3 PMC passes of this command on these kernel sources (hash %s), not this run" % (
+                    os.path.relpath(path, ROOT), khash)
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     out = {
         "metric": "train_patches_per_sec", "value": value, "unit": "patches/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: ssdn --noise_style gaussian --noise_value var, joint mode, "
                                "64x64 patches from 4 synthetic 1024x1024 micrographs, batch %d per GPU, alpha 0.75, "
-                               "tau 0.01, Adam; fp32 MFMA convolutions (Winograd F(2x2,3x3) for the wide 3x3 layers)" % args.batch,
-                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "patch": 64,
-                   "parallelism": "dp%d (flat fp32 grad all-reduce, %d floats)" % (world, sync.numel()) if world > 1 else "single GPU"},
-        "roofline": dict({"bound": "mfma", "kernel": nm, "kernel_note": notes[DOM],
-                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                          "launches": n0, "avg_launch_ms": ms0 / max(n0, 1),
-                          "gpu_time_share_in_warmup": warm[DOM][1] / max(sum(w[1] for w in warm.values()), 1e-9)},
-                         **({"mfma_pipe_frac": achieved * 4.0 / 9.0 / PEAK_FP32_MFMA_TFLOPS} if DOM in (3, 4) else {})),
+                               "tau 0.01, Adam; fp32 MFMA convolutions (Winograd F(2x2,3x3) for the wide 3x3 layers)" % batch,
+                   "per_gpu_batch": batch, "global_batch": batch * world, "patch": 64,
+                   "parallelism": "dp%d (in-place flat fp32 gradient all-reduce over RCCL, %d floats)" % (world, stepper.grads.live_numel)
+                                  if world > 1 else "single GPU",
+                   "execution": ("forward+backward replayed from 2 HIP graphs (one per flip axis, %d kernels each), eager "
+                                 "all-reduce + fused Adam" % (stepper.kernels_per_step or 0)) if use_graph
+                                else "every launch enqueued from Python (--graph off)"},
+        "roofline": {"bound": "mfma", "kernel": nm, "kernel_note": note,
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "peak_note": "fp32 MFMA dense peak %.1f TF x %.2f (algorithmic FLOPs per issued MFMA FLOP of this "
+                                  "kernel's algorithm)" % (PEAK_FP32_MFMA_TFLOPS, gain),
+                     "achieved_vs_direct_conv_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "launches": n0, "avg_launch_ms": ms0 / max(n0, 1),
+                     "events_region": ("%d eager steps right after the graph-replayed timed region (same kernels, same "
+                                       "batches; HIP events cannot bracket nodes inside a replayed graph)" % args.event_steps)
+                                      if use_graph else "the timed region",
+                     "gpu_time_share_in_warmup": warm[DOM][1] / max(sum(w[1] for w in warm.values()), 1e-9)},
         "whole_step_mfma_frac": value / world * FLOP_PER_PATCH_STEP / (PEAK_FP32_MFMA_TFLOPS * 1e12),
-        "other_mfma_kernels": [{"kernel": prof[k][0], "launches": prof[k][1], "avg_launch_ms": prof[k][2] / max(prof[k][1], 1),
-                                "achieved_tflops": prof[k][3] / (prof[k][2] * 1e-3) / 1e12 if prof[k][2] > 0 else 0.0}
+        "whole_step_note": "all algorithmic FLOPs of a step (67.90 GFLOP/patch) / step time / the fp32 direct-convolution "
+                           "MFMA peak",
+        "other_mfma_kernels": [{"kernel": KCLASS[k][0], "launches": prof[k][0],
+                                "avg_launch_ms": prof[k][1] / max(prof[k][0], 1),
+                                "achieved_tflops": prof[k][2] / (prof[k][1] * 1e-3) / 1e12 if prof[k][1] > 0 else 0.0,
+                                "frac_of_own_bound": (prof[k][2] / (prof[k][1] * 1e-3) / 1e12 /
+                                                      (PEAK_FP32_MFMA_TFLOPS * KCLASS[k][1])) if prof[k][1] > 0 else 0.0}
                                for k in others],
         "other_mfma_note": "three extra steps after the timed region with every MFMA launch bracketed by events",
         "all_conv_mfma_tflops": all_fl / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0,
-        "kernel_launches_per_step": launches / args.steps, "final_loss": last_loss,
+        "kernel_launches_per_step": (stepper.kernels_per_step if use_graph else launches / args.steps),
+        "host_launch_calls_per_step": launches / args.steps,
+        "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+        "final_loss": last_loss, "kernel_source_hash": khash,
     }
     if infer:
         out["inference"] = infer
+    if infer_large:
+        out["inference_large"] = infer_large
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(mics, args.cpu_seconds)
+        out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if args.infer_size:
+            out["cpu_baseline"]["inference"] = cpu_inference_baseline(args.infer_size)
+            out["inference"]["vs_cpu_baseline"] = infer["value"] / out["cpu_baseline"]["inference"]["value"]
     print(json.dumps(out))
 
 

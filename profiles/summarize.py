@@ -97,12 +97,18 @@ def counters(sub):
 fetch, write = counters("fetch"), counters("write")
 traffic = {}
 for k in sorted(set(fetch) | set(write)):
+    if not any(t in k for t in ("conv", "wino", "act_bwd", "bn_", "nms", "unrot", "rot4", "maxpool", "head", "adam")):
+        continue      # library kernels only (the stock ATen elementwise kernels are not this repo's)
     fk = fetch.get(k, {}).get("FETCH_SIZE", [0.0, 1])
     wk = write.get(k, {}).get("WRITE_SIZE", [0.0, 1])
     fkb, wkb = fk[0] / max(fk[1], 1), wk[0] / max(wk[1], 1)
     traffic[k] = {"launches": int(max(fk[1], wk[1])), "FETCH_SIZE_KB_avg": fkb, "WRITE_SIZE_KB_avg": wkb,
                   "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0}
-json.dump({"note": "per-launch averages over the profiled bench run; FETCH_SIZE doubled (gfx950 counts 128-B "
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402  (bench.py trusts this file only for the same kernel sources)
+
+json.dump({"kernel_source_hash": kernel_source_hash(),
+           "note": "per-launch averages over the profiled bench run; FETCH_SIZE doubled (gfx950 counts 128-B "
                    "requests at 64 B for wide streaming reads), WRITE_SIZE as is; separate PMC passes",
            "kernels": traffic}, open(os.path.join(here, tag + "_hbm_traffic.json"), "w"), indent=1)
 

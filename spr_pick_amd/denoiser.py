@@ -8,8 +8,9 @@ dictionary, for the configuration BASELINE.json runs: 1 channel, gaussian noise 
 
   * the random draws the reference takes implicitly (eps of the reparameterisation, the flip axis)
     can be passed in (``eps=``, ``eps_flip=``, ``flip_p=``) so runs can be replayed exactly;
-  * the PU loss never leaves the device: label counts come from the host copy of ``target`` and
-    the binomial table is cached per (N, tau) (reference: ``.item()`` + scipy every step);
+  * the PU loss never leaves the device: labels, masks and counts are device tensors and the binomial
+    table is cached per (B, tau) (reference: ``.item()`` + scipy every step), so a training step has no
+    host synchronisation and can be captured in a HIP graph (graph_step.py);
   * everything per-pixel is a fused HIP kernel (ops.py).
 """
 import numpy as np
@@ -31,42 +32,47 @@ def _sigmoid(x):
 
 class PuLoss(nn.Module):
     """BCE on labelled patches + slack * binomial generalised-expectation penalty on unlabelled
-    ones (utils/losses.py:303-349), evaluated with masks so that no device->host sync is needed."""
+    ones (utils/losses.py:303-349).
+
+    Evaluated entirely on the device from the label vector ``y`` (>= 0: labelled with that target, -1:
+    unlabelled), with masks instead of boolean indexing and device-side counts: no value ever travels to the
+    host, no shape depends on the data, so the step can be captured in a HIP graph and replayed on any batch.
+    The reference's ``binom.logpmf(arange(N+1), N, tau)`` (N = number of unlabelled patches, a different length
+    every batch) is row N of a (B+1) x (B+1) table computed once per (B, tau); entries k > N are masked out of
+    the softmax, which leaves the same N+1 terms."""
 
     def __init__(self):
         super().__init__()
         self._tables = {}
 
-    def _log_binom(self, n, tau, device):
-        key = (n, float(tau), str(device))
+    def _log_binom_table(self, B, tau, device):
+        key = (B, float(tau), str(device))
         if key not in self._tables:
-            t = stats.binom.logpmf(np.arange(0, n + 1), n, tau)
-            self._tables[key] = (torch.from_numpy(t).float().to(device),
-                                 torch.arange(0, n + 1, dtype=torch.float32, device=device))
+            k = np.arange(0, B + 1)
+            rows = np.zeros((B + 1, B + 1), dtype=np.float64)
+            for n in range(B + 1):
+                rows[n, :n + 1] = stats.binom.logpmf(k[:n + 1], n, tau)
+            self._tables[key] = (torch.from_numpy(rows).float().to(device),
+                                 torch.arange(0, B + 1, dtype=torch.float32, device=device))
         return self._tables[key]
 
-    def forward(self, tau, p, y_host, slack=4.0):
+    def forward(self, tau, p, y, slack=4.0):
         p = p.reshape(-1)
-        yh = y_host.reshape(-1).float()
-        lab_h = yh >= 0
-        unl_h = yh == -1
-        n_lab, n_unl = int(lab_h.sum()), int(unl_h.sum())
-        dev = p.device
-        # labels and the two masks travel in ONE pinned buffer, asynchronously: a pageable `.to(device)` is a
-        # synchronous copy, i.e. a full device sync in the middle of every step (measured: the host sat in it
-        # for half of the step and the GPU idled ~1 ms per step while the backward pass was being enqueued)
-        host = torch.stack([torch.where(lab_h, yh, torch.zeros_like(yh)), lab_h.float(), unl_h.float()])
-        if dev.type == "cuda":
-            host = host.pin_memory()
-        y, m_lab, m_unl = host.to(dev, non_blocking=True)
-        loss = 0
-        if n_lab > 0:
-            bce = -(y * torch.log(p) + (1 - y) * torch.log(1 - p))
-            loss = (bce * m_lab).sum() / n_lab
+        y = y.reshape(-1).to(device=p.device, dtype=torch.float32)
+        B = p.shape[0]
+        m_lab = (y >= 0).float()
+        m_unl = (y == -1).float()
+        n_lab, n_unl = m_lab.sum(), m_unl.sum()
+        yl = y * m_lab                                   # 0 where unlabelled (the term is masked anyway)
+        bce = -(yl * torch.log(p) + (1 - yl) * torch.log(1 - p))
+        loss = (bce * m_lab).sum() / n_lab.clamp_min(1.0)      # 0 when nothing is labelled, as the reference
         q_mu = (p * m_unl).sum()
         q_var = (p * (1 - p) * m_unl).sum()
-        log_binom, counts = self._log_binom(n_unl, tau, dev)
-        q = torch.softmax(-0.5 * (q_mu - counts) ** 2 / (q_var + 1e-7), dim=0)
+        table, counts = self._log_binom_table(B, tau, p.device)
+        log_binom = table.index_select(0, n_unl.long().reshape(1))[0]
+        valid = counts <= n_unl
+        logits = (-0.5 * (q_mu - counts) ** 2 / (q_var + 1e-7)).masked_fill(~valid, float("-inf"))
+        q = torch.softmax(logits, dim=0)
         return loss + slack * (-(log_binom * q).sum())
 
 
@@ -151,6 +157,16 @@ class Denoiser(nn.Module):
                                       "(noise_params_in is undefined in the reference, denoiser_v2.py:406)")
         return torch.nn.functional.softplus(est - 4.0) + 1e-3
 
+    def _labels_on_device(self, target):
+        """Patch labels [B,1] -> device.  A host tensor goes through pinned memory, asynchronously: a pageable
+        ``.to(device)`` is a synchronous copy, i.e. a full device sync in the middle of every step (measured in
+        round 1: the host sat in it for half of the step).  A device tensor (graph-captured step: a static buffer
+        the caller refills) is used as is."""
+        t = target if torch.is_tensor(target) else torch.as_tensor(target)
+        if t.device.type == "cuda":
+            return t
+        return t.detach().float().pin_memory().to(self.device, non_blocking=True)
+
     def _check_style(self):
         style = self.cfg[ConfigValue.NOISE_STYLE]
         if style is None or not style.startswith("gauss"):
@@ -164,7 +180,6 @@ class Denoiser(nn.Module):
         hm = data[DetectionDataset.HM]
         metadata = data[DetectionDataset.METADATA]
         gt = metadata.get(DetectionDataset.Metadata.GT) if isinstance(metadata, dict) else None
-        target_host = target.detach().cpu() if torch.is_tensor(target) else torch.as_tensor(target)
         inp = inp.to(self.device, dtype=torch.float32)
         if torch.is_tensor(hm):
             hm = hm.to(self.device)
@@ -176,7 +191,7 @@ class Denoiser(nn.Module):
             (net_out, hm_p), (_, hm_p_f) = model.forward_pair(inp, inp.flip(axis), eps, eps_flip)
             hm_p = _sigmoid(hm_p)
             hm_p_f = _sigmoid(hm_p_f.flip(axis))
-            pred_loss = self._pu(tau, hm_p, target_host)
+            pred_loss = self._pu(tau, hm_p, self._labels_on_device(target))
         else:
             net_out, hm_p = model(inp, eps=eps)
             hm_p = _sigmoid(hm_p)

@@ -1,0 +1,246 @@
+"""The training step as HIP graphs: launch-overhead-proof execution of
+``zero_grad -> run_pipeline(train) -> mean(loss).backward()`` (reference loop: train.py:329-338).
+
+A joint step is ~440 kernel launches; enqueued one by one from Python (ctypes call + workspace allocation +
+autograd bookkeeping per launch) the host needs ~17 ms per step, which is fine at 32 patches per GPU (21 ms of
+GPU work) and the bottleneck at 16 (BASELINE configs[3]: 128 patches over 8 GPUs) or with 16-bit convolutions.
+Here the whole forward + backward is captured once per flip axis (the pipeline flips along W or H, drawn per
+step) into a HIP graph — ``torch.cuda.CUDAGraph`` is hipGraph on ROCm — and replayed: one host call per step.
+Nothing in the captured region synchronises with the host or has a data-dependent shape (the PU loss is
+mask-based, denoiser.PuLoss; the reparameterisation noise comes from torch's graph-safe Philox stream).
+
+Gradients are written by the backward kernels straight into slices of ONE flat fp32 buffer (``FlatGrads``):
+  * both graphs write to the same addresses, so the optimiser sees the right gradients whichever was replayed;
+  * the data-parallel all-reduce runs in place on that buffer — no gather / scatter copies around the collective
+    (distributed.FlatGradAllReduce copies twice);
+  * the 1/world of the gradient average is folded into the loss before backward (exact for world = 2^k).
+The all-reduce and the Adam update stay outside the graphs (eager; Adam is the fused, capturable implementation, a
+handful of launches with the learning rate in a device tensor so the ramp needs no re-capture).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib, ops
+from .datasets import DetectionDataset
+from .params import PipelineOutput
+
+
+class FlatGrads:
+    """One flat fp32 buffer holding the gradient of every parameter; ``ops`` kernels write into its slices.
+
+    ``begin_step()`` replaces ``optimizer.zero_grad(set_to_none=True)``.  During backward every operator asks
+    ``dest(param)`` for the tensor to write the parameter's gradient into and gets the parameter's slice — once per
+    step; a second request in the same step (a parameter used by two operators) gets a fresh tensor, which autograd
+    then accumulates into the slice as usual.  Because the slice is handed to autograd as the gradient itself,
+    ``param.grad`` becomes a view of the buffer without a copy."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGrads: no parameters")
+        dev = self.params[0].device
+        self._layout(self.params, dev)
+        self.live_numel = self.flat.numel()
+
+    def _layout(self, order, dev):
+        total = sum(p.numel() for p in order)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views, off = {}, 0
+        for p in order:
+            n = p.numel()
+            self.views[p.data_ptr()] = self.flat[off:off + n].view(p.shape)
+            off += n
+        self._used = set()
+
+    def compact(self):
+        """After one backward pass: parameters that received no gradient (12 tensors of the joint model, SURVEY.md
+        §8a A12) move to the tail of the buffer, so that the collective covers the live prefix only."""
+        live = [p for p in self.params if p.grad is not None]
+        dead = [p for p in self.params if p.grad is None]
+        for p in self.params:
+            p.grad = None
+        self._layout(live + dead, self.flat.device)
+        self.live_numel = sum(p.numel() for p in live)
+
+    def adopt_strays(self):
+        """A parameter used by two operators in one step gets the SUM of their gradients from autograd — a new
+        tensor, not the slice one of them wrote to.  Copy such gradients into their slice and re-point ``.grad``
+        (no launch at all when every parameter has one consumer, which is the joint model's case)."""
+        n = 0
+        for p in self.params:
+            if p.grad is not None:
+                v = self.views[p.data_ptr()]
+                if p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                    p.grad = v.view(v.shape)
+                    n += 1
+        return n
+
+    def check_adopted(self):
+        """Every live parameter's ``.grad`` must BE its slice; otherwise the flat buffer would silently hold
+        stale data for the collective."""
+        for p in self.params:
+            if p.grad is not None and p.grad.data_ptr() != self.views[p.data_ptr()].data_ptr():
+                raise _lib.SprkError("FlatGrads: the gradient of a %s parameter is not in the flat buffer"
+                                     % (tuple(p.shape),))
+
+    def begin_step(self):
+        self._used.clear()
+        for p in self.params:
+            p.grad = None
+
+    def dest(self, w):
+        key = w.data_ptr()
+        v = self.views.get(key)
+        if v is None or key in self._used or v.shape != w.shape:
+            return torch.empty_like(w)
+        self._used.add(key)
+        return v.view(v.shape)      # a fresh tensor object: autograd adopts a gradient only if nobody else holds it
+
+    def all_reduce(self, world):
+        """SUM over ranks, in place (the loss was pre-divided by ``world``)."""
+        if world > 1:
+            dist.all_reduce(self.flat[:self.live_numel], op=dist.ReduceOp.SUM)
+
+    def __enter__(self):
+        ops.set_grad_destinations(self)
+        return self
+
+    def __exit__(self, *exc):
+        ops.set_grad_destinations(None)
+        return False
+
+
+def make_adam(params, lr=1e-4, betas=(0.9, 0.99)):
+    """Adam as the reference configures it (train.py:128-140), in the fused + capturable form: state and learning
+    rate live on the device, so a step never synchronises and the ramped rate is set with ``set_lr``."""
+    params = list(params)
+    dev = params[0].device
+    return torch.optim.Adam(params, lr=torch.tensor(float(lr), dtype=torch.float32, device=dev), betas=betas,
+                            capturable=True, fused=True)
+
+
+def set_lr(optimizer, lr):
+    for group in optimizer.param_groups:
+        if torch.is_tensor(group["lr"]):
+            group["lr"].fill_(float(lr))
+        else:
+            group["lr"] = lr
+
+
+class GraphedTrainStep:
+    """``step(inp, target) -> outputs`` with the forward + backward replayed from a HIP graph.
+
+    outputs: the pipeline's dictionary (static tensors, overwritten by the next call — read or clone what must
+    survive).  Gradients are in ``self.grads.flat`` / ``param.grad`` afterwards; the caller runs
+    ``self.grads.all_reduce(world)`` and the optimiser.  ``graph=False`` runs the same step eagerly (same kernels,
+    same flat gradients) — the path the roofline leg of bench.py brackets with events."""
+
+    PIN_SLOTS = 8
+
+    def __init__(self, denoiser, batch, patch, alpha, tau, world=1, mode="joint", graph=True, eager_warmup=2):
+        self.den = denoiser
+        self.dev = denoiser.device
+        self.alpha, self.tau, self.world, self.mode = alpha, tau, world, mode
+        self.use_graph = graph
+        self.grads = FlatGrads(denoiser.parameters())
+        self.inp = torch.zeros(batch, 1, patch, patch, dtype=torch.float32, device=self.dev)
+        self.tgt = torch.full((batch, 1), -1.0, dtype=torch.float32, device=self.dev)
+        self._pins = [torch.empty(batch, 1, dtype=torch.float32).pin_memory() for _ in range(self.PIN_SLOTS)]
+        self._pin_events = [None] * self.PIN_SLOTS
+        self._pin_next = 0
+        self._empty = torch.zeros(0, device=self.dev)
+        self._graphs = {}
+        self._pool = None
+        self._warm = eager_warmup
+        self._compacted = False
+        self.kernels_per_step = None
+
+    # ---- one pass, eager (also what gets captured) ---------------------------------------------------
+    def _pass(self, flip_p):
+        data = DetectionDataset.make_batch(self.inp, self.tgt, hm=self._empty, hm_small=self._empty)
+        if self.mode == "joint":
+            o = self.den.run_pipeline(data, self.alpha, self.tau, train=True, flip_p=flip_p)
+        else:
+            o = self.den.run_pipeline(data, train=True)
+        loss = torch.mean(o[PipelineOutput.LOSS])
+        if self.world > 1:
+            loss = loss / self.world
+        loss.backward()
+        self.grads.adopt_strays()
+        return o
+
+    def _eager(self, flip_p):
+        self.grads.begin_step()
+        with self.grads:
+            o = self._pass(flip_p)
+        if not self._compacted:
+            self.grads.compact()
+            self._compacted = True
+            # the first pass wrote to the old layout: redo it so this step's gradients are in place
+            self.grads.begin_step()
+            with self.grads:
+                o = self._pass(flip_p)
+            self.grads.check_adopted()
+        return o
+
+    def _capture(self, axis_key, flip_p):
+        L = _lib.lib()
+        g = torch.cuda.CUDAGraph()
+        self.grads.begin_step()
+        torch.cuda.synchronize(self.dev)
+        n0 = L.sprk_launch_count()
+        with torch.cuda.graph(g, pool=self._pool):
+            with self.grads:
+                o = self._pass(flip_p)
+        self.kernels_per_step = L.sprk_launch_count() - n0
+        self.grads.check_adopted()
+        if self._pool is None:
+            self._pool = g.pool()
+        self._graphs[axis_key] = (g, o)
+
+    # ---- public -----------------------------------------------------------------------------------
+    def load(self, inp, target):
+        """Copy a batch into the static buffers (asynchronously; labels go through a ring of pinned buffers)."""
+        self.inp.copy_(inp.to(self.dev, non_blocking=True) if inp.device != self.dev else inp, non_blocking=True)
+        t = target if torch.is_tensor(target) else torch.as_tensor(target)
+        if t.device.type == "cuda":
+            self.tgt.copy_(t.reshape(self.tgt.shape), non_blocking=True)
+            return
+        k = self._pin_next
+        self._pin_next = (k + 1) % self.PIN_SLOTS
+        if self._pin_events[k] is not None:
+            self._pin_events[k].synchronize()       # the copy that last read this slot has finished (normally long ago)
+        self._pins[k].copy_(t.reshape(self.tgt.shape).float())
+        self.tgt.copy_(self._pins[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        self._pin_events[k] = ev
+
+    def prepare(self, inp, target):
+        """Eager warm-up passes (lazy one-time set-up inside the library, the gradient layout) and the capture of
+        both flip-axis graphs, on the given batch.  Leaves the gradients of that batch in place."""
+        self.load(inp, target)
+        while self._warm > 0:
+            self._warm -= 1
+            self._eager(0.25)
+        if not self._compacted:
+            self._eager(0.25)
+        if self.use_graph:
+            for key, p in (("w", 0.25), ("h", 0.75)):
+                if key not in self._graphs and (self.mode == "joint" or key == "w"):
+                    self._capture(key, p)
+
+    def __call__(self, inp, target, flip_p=None, eager=False):
+        self.load(inp, target)
+        p = float(np.random.rand()) if flip_p is None else float(flip_p)
+        if eager or not self.use_graph or self._warm > 0 or not self._compacted:
+            self._warm -= 1
+            return self._eager(p)
+        key = "w" if (p <= 0.5 or self.mode != "joint") else "h"
+        if key not in self._graphs:
+            self._capture(key, 0.25 if key == "w" else 0.75)
+        g, o = self._graphs[key]
+        g.replay()
+        return o

@@ -35,6 +35,25 @@ def _need_gpu(*ts):
                                  "there is no CPU path" % (t.dtype, t.device))
 
 
+_GRAD_DEST = None
+
+
+def set_grad_destinations(flat):
+    """``flat``: an object with ``dest(param) -> tensor`` (graph_step.FlatGrads) or None.  While set, the backward
+    kernels write parameter gradients into the tensors it hands out (slices of one flat buffer) instead of fresh
+    allocations."""
+    global _GRAD_DEST
+    _GRAD_DEST = flat
+
+
+def _grad_like(w):
+    """Where the gradient of parameter ``w`` is written: its slice of the flat gradient buffer when one is
+    registered (as a fresh view object, so that autograd adopts it as ``w.grad`` without a copy), else new memory."""
+    if _GRAD_DEST is not None:
+        return _GRAD_DEST.dest(w)
+    return torch.empty_like(w)
+
+
 def _ws(nbytes, like):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
 
@@ -92,13 +111,13 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.act = act
         ctx.up_out = up_out
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None)
+        ctx.save_for_backward(x, x2, w, y if act != ACT_NONE else None, bias)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         L = _lib.lib()
-        x, x2, w, y = ctx.saved_tensors
+        x, x2, w, y, bias = ctx.saved_tensors
         g = ctx.geom
         gy = gy.contiguous()
         _need_gpu(gy)
@@ -112,7 +131,7 @@ class _Conv2dFn(torch.autograd.Function):
             else:
                 gpre = gy
             if need_b:
-                gb = torch.empty(g.Cout, dtype=torch.float32, device=gy.device)
+                gb = _grad_like(bias)
             nb = L.sprk_act_bwd_ws_bytes(g.N, g.Cout, g.Hout * g.Wout)
             ws = _ws(nb, gy)
             check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre) if gpre is not gy else None, _p(gb), ctx.act,
@@ -120,7 +139,7 @@ class _Conv2dFn(torch.autograd.Function):
         else:
             gpre = gy
         if ctx.needs_input_grad[2]:
-            gw = torch.empty_like(w)
+            gw = _grad_like(w)
             nb = L.sprk_conv2d_bwd_weight_ws_bytes(ctypes.byref(g))
             ws = _ws(nb, gy)
             check(L.sprk_conv2d_bwd_weight(_p(x), _p(x2), _p(gpre), _p(gw), ctypes.byref(g), _p(ws), nb, _stream(x)),
@@ -265,19 +284,22 @@ class _BNTrainFn(torch.autograd.Function):
                                       _p(mean[g]), _p(invstd[g]), Ng, C, H * W, momentum, eps, int(relu), _p(ws), nb,
                                       _stream(x)), "sprk_bn_train_fwd")
         ctx.relu, ctx.groups = relu, groups
-        ctx.save_for_backward(x, y, gamma, mean, invstd)
+        ctx.save_for_backward(x, y, gamma, mean, invstd, beta)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, y, gamma, mean, invstd = ctx.saved_tensors
+        x, y, gamma, mean, invstd, beta = ctx.saved_tensors
         gy = gy.contiguous()
         N, C, H, W = x.shape
         groups = ctx.groups
         Ng = N // groups
         gx = torch.empty_like(x)
-        gg = torch.empty((groups, C), dtype=torch.float32, device=x.device)
-        gb = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+        if groups == 1:     # straight into the parameters' gradient tensors
+            gg, gb = _grad_like(gamma).view(1, C), _grad_like(beta).view(1, C)
+        else:
+            gg = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+            gb = torch.empty((groups, C), dtype=torch.float32, device=x.device)
         L = _lib.lib()
         nb = L.sprk_bn_ws_bytes(Ng, C, H * W)
         ws = _ws(nb, x)
@@ -287,9 +309,9 @@ class _BNTrainFn(torch.autograd.Function):
                                       _p(gx[sl]), _p(gg[g]), _p(gb[g]), Ng, C, H * W, int(ctx.relu), _p(ws), nb,
                                       _stream(gy)), "sprk_bn_train_bwd")
         if groups > 1:
-            gg, gb = gg.sum(0), gb.sum(0)
+            gg, gb = torch.sum(gg, 0, out=_grad_like(gamma)), torch.sum(gb, 0, out=_grad_like(beta))
         else:
-            gg, gb = gg[0], gb[0]
+            gg, gb = gg.view(C), gb.view(C)
         return gx, gg, gb, None, None, None, None, None, None
 
 

@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from . import cfg as cfg_mod
-from . import checkpoint, distributed, feed as feed_mod, picks
+from . import checkpoint, distributed, feed as feed_mod, graph_step, picks
 from .algorithms import nms_device
 from .datasets import DetectionDataset
 from .denoiser import Denoiser
@@ -65,7 +65,7 @@ def tensor_to_png(img, path):
 
 class DenoiserTrainer:
     def __init__(self, cfg, mode, state=None, runs_dir=cfg_mod.DEFAULT_RUN_DIR, run_dir=None, alpha=0.5, tau=0.01,
-                 bb=32, device=None, seed=0):
+                 bb=32, device=None, seed=0, graph=True):
         self.runs_dir = os.path.abspath(runs_dir)
         self._run_dir = run_dir
         self.cfg = cfg
@@ -81,7 +81,8 @@ class DenoiserTrainer:
             torch.cuda.set_device(self.device)      # one process drives one GPU (kernels go to ITS streams)
         self._denoiser = None
         self._optimizer = None
-        self._grad_sync = None
+        self._stepper = None
+        self.graph = graph and os.environ.get("SPRK_GRAPH", "1") != "0"
         self._metrics_file = None
         self.trainfeed, self.testfeed = None, None
 
@@ -99,8 +100,9 @@ class DenoiserTrainer:
         for _, p in self.denoiser.named_parameters():
             p.requires_grad = True
         params = [p for p in self.denoiser.parameters() if p.requires_grad]
-        self._optimizer = torch.optim.Adam(params, betas=(0.9, 0.99))
-        self._grad_sync = distributed.FlatGradAllReduce(params, self.world)
+        # Adam(beta = (0.9, 0.99)) as train.py:128-140, fused + capturable (state and learning rate on the device)
+        self._optimizer = graph_step.make_adam(params, lr=BASE_LR, betas=(0.9, 0.99))
+        self._stepper = None      # built at the first training step (needs the per-rank batch shape)
 
     def new_target(self):
         torch.manual_seed(self.seed)            # same initial weights on every rank
@@ -134,8 +136,7 @@ class DenoiserTrainer:
     @property
     def optimizer(self):
         lr = self.learning_rate
-        for group in self._optimizer.param_groups:
-            group["lr"] = lr
+        graph_step.set_lr(self._optimizer, lr)
         return self._optimizer
 
     # ---- the loop ------------------------------------------------------------------------------
@@ -188,14 +189,15 @@ class DenoiserTrainer:
             image_count = data[DetectionDataset.INPUT].shape[0] * self.world
             denoiser.train()
             denoiser.unfill()
-            optimizer = self.optimizer
-            optimizer.zero_grad()
-            if joint:
-                outputs = denoiser.run_pipeline(data, self.alpha, self.tau, train=True)
-            else:
-                outputs = denoiser.run_pipeline(data, train=True)
-            torch.mean(outputs[PipelineOutput.LOSS]).backward()
-            self._grad_sync()
+            optimizer = self.optimizer          # sets the ramped learning rate (a device scalar)
+            if self._stepper is None:
+                inp0 = data[DetectionDataset.INPUT]
+                self._stepper = graph_step.GraphedTrainStep(denoiser, inp0.shape[0], inp0.shape[-1], self.alpha, self.tau,
+                                                            world=self.world, mode=self.mode, graph=self.graph)
+            # zero_grad + forward + mean(loss).backward(): replayed from a HIP graph (graph_step.py), the gradients
+            # land in one flat buffer; then the in-place all-reduce over the ranks and the Adam update
+            outputs = self._stepper(data[DetectionDataset.INPUT], data[DetectionDataset.TARGET])
+            self._stepper.grads.all_reduce(self.world)
             optimizer.step()
 
             with torch.no_grad():

@@ -349,3 +349,49 @@ def test_filled_inference_is_translation_consistent(oracle_state):
         print(key, "max |diff| %.3e of scale %.3e; bitwise equal: %s" % (worst, scale, bool(torch.equal(a, b))))
         assert worst <= 2e-5 * scale + 1e-7, key
     den.unfill()
+
+
+def test_filled_inference_4096_and_nms(oracle_state):
+    """BASELINE configs[2] at full size: one 4096x4096 micrograph through the filled forward (sigma net,
+    posterior mean, clamped sigmoid) and the NMS.  4096^2 crosses the 2^31-element / 2 GB buffer-range limits the
+    kernels special-case, so nothing smaller exercises those paths.  Checks:
+      * three 1024^2 interior windows (top-left, centre, bottom-right quadrant) against the SAME network on the
+        cropped input (translation consistency, as above) at 2e-5 of the window's max |value|;
+      * the picks of the device NMS on the full 4096^2 score map against the C oracle on that same map,
+        coordinates and scores bit-exact (reference: utils/algorithms.py:59-103, call train.py:564, r = 18,
+        threshold 0.02);
+      * the reference's border post-filter (train.py:563-571) keeps only interior picks."""
+    from oracle import nms
+    from spr_pick_amd import Denoiser, DetectionDataset, nms_device, picks, synthetic
+    from spr_pick_amd.params import PipelineOutput as P
+    den = Denoiser(make_cfg(), device="cuda:0", mode="joint")
+    den.load_state_dict({"models." + k: v for k, v in oracle_state.items()}, strict=False)
+    den.eval()
+    den.fill()
+    S, C = 4096, 1024
+    img = torch.from_numpy(synthetic.micrograph(5, size=S)[0].astype(np.float32) / 255.0).cuda()[None, None]
+    with torch.no_grad():
+        full = den.run_pipeline(DetectionDataset.make_batch(img, torch.zeros(1, 1)), train=False,
+                                eps=torch.zeros_like(img))
+        mu, det = full[P.IMG_MU][0, 0].clone(), full[P.DETECT][0, 0].clone()
+        del full
+        torch.cuda.empty_cache()
+        m = 448
+        for off_y, off_x in ((0, 0), (1536, 1536), (3072, 2048)):
+            crop = img[:, :, off_y:off_y + C, off_x:off_x + C].contiguous()
+            part = den.run_pipeline(DetectionDataset.make_batch(crop, torch.zeros(1, 1)), train=False,
+                                    eps=torch.zeros_like(crop))
+            for name, whole, key in (("mu", mu, P.IMG_MU), ("detect", det, P.DETECT)):
+                a = whole[off_y + m:off_y + C - m, off_x + m:off_x + C - m]
+                b = part[key][0, 0, m:C - m, m:C - m]
+                scale, worst = float(a.abs().max()), float((a - b).abs().max())
+                assert worst <= 2e-5 * scale + 1e-7, (name, off_y, off_x, worst, scale)
+    den.unfill()
+    s, c = nms_device(det, 18, 0.02)
+    s, c = s.cpu().numpy(), c.cpu().numpy()
+    s2, c2 = nms.nms_c(det.cpu().numpy(), 18, 0.02)
+    assert len(s) == len(s2) and len(s) > 1000, (len(s), len(s2))
+    assert np.array_equal(c, c2) and np.array_equal(s, s2)
+    keep = picks.filter_picks(s, c, (S, S))
+    kc = np.asarray(keep[1])
+    assert len(kc) and kc.min() > 30 and kc.max() < S - 30
