@@ -47,6 +47,39 @@ def load_micrographs(image_path, label_path=None, radius=3, bb=24):
     return groups, names
 
 
+class PinnedRing:
+    """Asynchronous host -> device upload of small per-step arrays through a ring of pinned buffers.
+
+    One pinned buffer re-used every step is a race once the host runs ahead of the device (a replayed HIP graph
+    takes the host microseconds per step): the next step's values would overwrite the buffer before the previous
+    copy has executed.  Each slot remembers the event of the copy that last read it and is re-used only after
+    that copy has completed (normally long ago: ``slots`` steps back)."""
+
+    def __init__(self, shape, dtype, device, slots=8):
+        self.device = torch.device(device)
+        cuda = self.device.type == "cuda"
+        self._bufs = [torch.empty(shape, dtype=dtype).pin_memory() if cuda else torch.empty(shape, dtype=dtype)
+                      for _ in range(slots)]
+        self._events = [None] * slots
+        self._next = 0
+
+    def upload(self, host_tensor, out=None):
+        k = self._next
+        self._next = (k + 1) % len(self._bufs)
+        if self._events[k] is not None:
+            self._events[k].synchronize()
+        self._bufs[k].copy_(host_tensor.reshape(self._bufs[k].shape))
+        if out is None:
+            out = self._bufs[k].to(self.device, non_blocking=True)
+        else:
+            out.copy_(self._bufs[k], non_blocking=True)
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._events[k] = ev
+        return out
+
+
 class PatchFeed:
     """Endless stream of training batches in the DetectionDataset list layout."""
 
@@ -76,8 +109,7 @@ class PatchFeed:
         self.offsets = torch.from_numpy(offsets).to(self.device)
         self.dims = torch.tensor([[s[0], s[1]] for s in self._shape], dtype=torch.int32, device=self.device)
         self.n_mics = len(arrays)
-        self._items_host = torch.empty((batch, 4), dtype=torch.int32).pin_memory() if self.device.type == "cuda" \
-            else torch.empty((batch, 4), dtype=torch.int32)
+        self._items_ring = PinnedRing((batch, 4), torch.int32, self.device)
 
     def draw(self):
         """One batch worth of sampler draws -> (items int32 [B,4] = image, x, y, flip; labels [B,1];
@@ -98,8 +130,7 @@ class PatchFeed:
         """items int32 [B,4] (host) -> float32 [B,1,P,P] on the device."""
         B = items.shape[0]
         if B == self.batch:
-            self._items_host.copy_(torch.from_numpy(items))
-            dev_items = self._items_host.to(self.device, non_blocking=True)
+            dev_items = self._items_ring.upload(torch.from_numpy(items))
         else:
             dev_items = torch.from_numpy(np.ascontiguousarray(items)).to(self.device)
         out = torch.empty((B, 1, self.patch, self.patch), dtype=torch.float32, device=self.device)

@@ -23,6 +23,7 @@ import torch.distributed as dist
 
 from . import _lib, ops
 from .datasets import DetectionDataset
+from .feed import PinnedRing
 from .params import PipelineOutput
 
 
@@ -137,8 +138,6 @@ class GraphedTrainStep:
     ``self.grads.all_reduce(world)`` and the optimiser.  ``graph=False`` runs the same step eagerly (same kernels,
     same flat gradients) — the path the roofline leg of bench.py brackets with events."""
 
-    PIN_SLOTS = 8
-
     def __init__(self, denoiser, batch, patch, alpha, tau, world=1, mode="joint", graph=True, eager_warmup=2):
         self.den = denoiser
         self.dev = denoiser.device
@@ -147,10 +146,9 @@ class GraphedTrainStep:
         self.grads = FlatGrads(denoiser.parameters())
         self.inp = torch.zeros(batch, 1, patch, patch, dtype=torch.float32, device=self.dev)
         self.tgt = torch.full((batch, 1), -1.0, dtype=torch.float32, device=self.dev)
-        self._pins = [torch.empty(batch, 1, dtype=torch.float32).pin_memory() for _ in range(self.PIN_SLOTS)]
-        self._pin_events = [None] * self.PIN_SLOTS
-        self._pin_next = 0
+        self._tgt_ring = PinnedRing((batch, 1), torch.float32, self.dev)
         self._empty = torch.zeros(0, device=self.dev)
+        self._side = torch.cuda.Stream(self.dev)      # every forward+backward of this object runs (or is captured) here
         self._graphs = {}
         self._pool = None
         self._warm = eager_warmup
@@ -172,17 +170,26 @@ class GraphedTrainStep:
         return o
 
     def _eager(self, flip_p):
-        self.grads.begin_step()
-        with self.grads:
-            o = self._pass(flip_p)
-        if not self._compacted:
-            self.grads.compact()
-            self._compacted = True
-            # the first pass wrote to the old layout: redo it so this step's gradients are in place
+        # Eager passes run on the same side stream the graphs are captured on.  autograd binds a parameter's
+        # AccumulateGrad node to the stream it was first used on and re-uses the node for as long as any earlier
+        # autograd graph is alive (e.g. the caller still holds last step's outputs): a node born on the default
+        # stream would drag that stream into a later capture (cross-stream event waits inside the captured
+        # region; on ROCm the capture then dies in hipStreamEndCapture).
+        cur = torch.cuda.current_stream(self.dev)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
             self.grads.begin_step()
             with self.grads:
                 o = self._pass(flip_p)
-            self.grads.check_adopted()
+            if not self._compacted:
+                self.grads.compact()
+                self._compacted = True
+                # the first pass wrote to the old layout: redo it so this step's gradients are in place
+                self.grads.begin_step()
+                with self.grads:
+                    o = self._pass(flip_p)
+                self.grads.check_adopted()
+        cur.wait_stream(self._side)
         return o
 
     def _capture(self, axis_key, flip_p):
@@ -191,7 +198,7 @@ class GraphedTrainStep:
         self.grads.begin_step()
         torch.cuda.synchronize(self.dev)
         n0 = L.sprk_launch_count()
-        with torch.cuda.graph(g, pool=self._pool):
+        with torch.cuda.graph(g, pool=self._pool, stream=self._side):
             with self.grads:
                 o = self._pass(flip_p)
         self.kernels_per_step = L.sprk_launch_count() - n0
@@ -208,15 +215,7 @@ class GraphedTrainStep:
         if t.device.type == "cuda":
             self.tgt.copy_(t.reshape(self.tgt.shape), non_blocking=True)
             return
-        k = self._pin_next
-        self._pin_next = (k + 1) % self.PIN_SLOTS
-        if self._pin_events[k] is not None:
-            self._pin_events[k].synchronize()       # the copy that last read this slot has finished (normally long ago)
-        self._pins[k].copy_(t.reshape(self.tgt.shape).float())
-        self.tgt.copy_(self._pins[k], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.dev))
-        self._pin_events[k] = ev
+        self._tgt_ring.upload(t.float(), out=self.tgt)
 
     def prepare(self, inp, target):
         """Eager warm-up passes (lazy one-time set-up inside the library, the gradient layout) and the capture of
