@@ -203,6 +203,10 @@ def main():
                     help="replay the forward+backward from HIP graphs (on) or enqueue every launch from Python (off)")
     ap.add_argument("--event-steps", type=int, default=10,
                     help="eager steps after the timed region whose dominant-kernel launches are bracketed by HIP events")
+    ap.add_argument("--dtype", choices=("f32", "bf16", "f16"), default="f32",
+                    help="operand precision of the U-Nets' MFMA convolutions in the headline (timed) region")
+    ap.add_argument("--also-dtype", choices=("none", "bf16", "f16"), default="bf16",
+                    help="second, shorter timed region with this operand precision (reported under train_<dtype>)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--infer-size", type=int, default=1024, help="side of the small inference micrograph (0 = skip)")
@@ -232,6 +236,8 @@ def main():
     params = [p for p in den.parameters() if p.requires_grad]
     opt = graph_step.make_adam(params, lr=1e-4, betas=(0.9, 0.99))
     use_graph = args.graph != "off"
+    if args.dtype != "f32":
+        den.set_conv_dtype(args.dtype)
     stepper = graph_step.GraphedTrainStep(den, batch, 64, 0.75, 0.01, world=world, graph=use_graph)
     nb = min(16, args.steps + args.warmup)
     batches = synthetic.patch_batches(nb, batch, mics, seed=100 + rank, device=dev)
@@ -312,6 +318,48 @@ def main():
     all_ms = extra_dom[1] + sum(prof[k][1] for k in others)
     all_fl = extra_dom[2] + sum(prof[k][2] for k in others)
 
+    # second training leg: the same step with 16-bit MFMA operands in the U-Nets (BASELINE configs[4]); new graphs
+    second = None
+    if args.also_dtype not in ("none", args.dtype):
+        n16 = den.set_conv_dtype(args.also_dtype)
+        st2 = graph_step.GraphedTrainStep(den, batch, 64, 0.75, 0.01, world=world, graph=use_graph)
+        st2.grads = stepper.grads          # same flat gradient buffer (the optimiser's .grad views stay valid)
+        st2._compacted = True
+
+        def step2(i):
+            inp, tgt = batches[i % nb]
+            o2 = st2(inp, tgt)
+            st2.grads.all_reduce(world)
+            opt.step()
+            return o2
+        c16_0 = L.sprk_conv16_launch_count()
+        st2._eager(0.25)
+        c16_per_step = L.sprk_conv16_launch_count() - c16_0
+        st2._warm = 0
+        st2.prepare(*batches[0])
+        for i in range(3):
+            step2(i)
+        fence()
+        k2 = max(20, args.steps // 4)
+        t0 = time.perf_counter()
+        for i in range(k2):
+            o2 = step2(i)
+        fence()
+        dt2 = time.perf_counter() - t0
+        t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt2 = float(t.item())
+        second = {"metric": "train_patches_per_sec", "dtype": args.also_dtype, "value": world * batch * k2 / dt2,
+                  "unit": "patches/s", "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
+                  "final_loss": float(torch.mean(o2[P.LOSS].detach())),
+                  "conv_layers_requesting_16bit": n16, "conv_launches_on_16bit_kernels_per_step": c16_per_step,
+                  "note": "same step, U-Net MFMA operands rounded to %s (fp32 tensors, master weights, accumulation; "
+                          "backward-weight still on the fp32 kernels); the library takes the 16-bit kernel where it "
+                          "is the faster one" % args.also_dtype}
+        del o2, st2
+        den.set_conv_dtype(args.dtype)
+
     infer = infer_large = None
     if rank == 0:
         del o
@@ -351,10 +399,12 @@ def main():
     out = {
         "metric": "train_patches_per_sec", "value": value, "unit": "patches/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: ssdn --noise_style gaussian --noise_value var, joint mode, "
                                "64x64 patches from 4 synthetic 1024x1024 micrographs, batch %d per GPU, alpha 0.75, "
-                               "tau 0.01, Adam; fp32 MFMA convolutions (Winograd F(2x2,3x3) for the wide 3x3 layers)" % batch,
+                               "tau 0.01, Adam; %s" % (batch, "fp32 MFMA convolutions (Winograd F(2x2,3x3) for the wide 3x3 layers)"
+                                                    if args.dtype == "f32" else
+                                                    "%s-operand MFMA convolutions in the U-Nets where faster, fp32 elsewhere" % args.dtype),
                    "per_gpu_batch": batch, "global_batch": batch * world, "patch": 64,
                    "parallelism": "dp%d (in-place flat fp32 gradient all-reduce over RCCL, %d floats)" % (world, stepper.grads.live_numel)
                                   if world > 1 else "single GPU",
@@ -389,6 +439,8 @@ def main():
         "host_enqueue_wall_ms_per_step": t_enq / args.steps * 1e3,
         "final_loss": last_loss, "kernel_source_hash": khash,
     }
+    if second:
+        out["train_" + second["dtype"]] = second
     if infer:
         out["inference"] = infer
     if infer_large:

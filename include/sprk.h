@@ -48,7 +48,24 @@ typedef struct sprk_conv_geom {
     int32_t N, C1, C2, Hin, Win, up1;
     int32_t Cout, Hout, Wout;
     int32_t KH, KW, stride, dil, pad_top, pad_left;
+    int32_t dtype;   /* SPRK_DT_*: precision of the MFMA OPERANDS (see below); tensors are fp32 either way */
 } sprk_conv_geom;
+
+/* Operand precision of the matrix-core convolutions (BASELINE configs[4]: "fp16 MFMA conv").
+ * SPRK_DT_F32 (0, the default): v_mfma_f32_16x16x4_f32 — exact fp32 products, what every parity figure of the fp32
+ * path refers to.  SPRK_DT_BF16 / SPRK_DT_F16: the two operands of each product (activation or gradient, and
+ * weight) are rounded to bf16 / fp16 on their way into v_mfma_f32_16x16x32_{bf16,f16}; products and sums are fp32;
+ * inputs, outputs, master weights and weight gradients stay fp32 tensors.  It is a REQUEST: layers the 16-bit
+ * kernels do not cover (strided / dilated / tiny detector layers, < 33 output channels, maps below 16x16) run in
+ * fp32; sprk_conv16_launch_count() tells which path ran.  Error bound per output: 2u * sum_k |a_k w_k| with
+ * u = 2^-8 (bf16) / 2^-11 (fp16). */
+#define SPRK_DT_F32 0
+#define SPRK_DT_BF16 1
+#define SPRK_DT_F16 2
+#define SPRK_DT_MASK 0xff
+/* or-ed into dtype: take the 16-bit kernel for every layer it covers, also where the library's own choice would be
+ * the fp32 Winograd kernel because it is faster there (wide 3x3 layers on planes >= 64x64); used by the parity tests */
+#define SPRK_DT_FORCE 0x100
 
 /* Optional fused epilogue of sprk_conv2d_fwd, applied in this order:
  *   v = acc (+ res[n,co,oy+res_off,ox+res_off])            res: [N,Cout,res_h,res_w]
@@ -71,6 +88,9 @@ int sprk_version(void);
 long sprk_launch_count(void);
 /* number of convolutions (forward or backward-data) that took the Winograd F(2x2,3x3) kernel (diagnostics) */
 long sprk_wino_launch_count(void);
+/* number of convolution launches (forward, backward-data or backward-weight) that ran on the 16-bit-operand
+ * kernels (diagnostics / tests) */
+long sprk_conv16_launch_count(void);
 /* debug switch: 1 = route convolutions through the direct (non-MFMA) kernels */
 void sprk_set_naive(int on);
 

@@ -30,19 +30,23 @@ SHAPES = {
     "cin32->96@64": (128, 32, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
     "cin64->96@64": (128, 64, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
 }
-which = sys.argv[1:] or list(SHAPES)
+DT = 0
+args = sys.argv[1:]
+if args and args[0] in _lib.DTYPES:
+    DT = _lib.DTYPES[args.pop(0)]
+which = args or list(SHAPES)
 reps = 20
 for name in which:
     N, C1, C2, H, W, up1, Cout, K, pad = SHAPES[name]
     h1, w1 = (H // 2, W // 2) if up1 else (H, W)
     x = torch.randn(N, C1, h1, w1, device=d); x2 = torch.randn(N, C2, H, W, device=d) if C2 else None
     w = torch.randn(Cout, C1 + C2, K, K, device=d) * 0.05
-    g = ops.make_geom(x, x2, w, bool(up1), 1, 1, pad)
+    g = ops.make_geom(x, x2, w, bool(up1), 1, 1, pad, dtype=DT)
     y = torch.empty(N, Cout, g.Hout, g.Wout, device=d); gy = torch.randn_like(y)
     gin = torch.empty(N, C1 + C2, H, W, device=d); gw = torch.empty_like(w)
     flops = 2.0 * N * g.Hout * g.Wout * Cout * (C1 + C2) * K * K
     ep = _lib.ConvEpilogue(None, None, None, None, 0, 0, 0, 1)
-    st = ops._stream()
+    st = ops._stream(x)
     def fwd():
         nb = L.sprk_conv2d_fwd_ws_bytes(ctypes.byref(g)); ws = ops._ws(nb, x)
         _lib.check(L.sprk_conv2d_fwd(ops._p(x), ops._p(x2), ops._p(w), ops._p(y), ctypes.byref(g), ctypes.byref(ep), ops._p(ws), nb, st), "f")
@@ -61,4 +65,6 @@ for name in which:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         res.append("%s %7.1f us %6.1f TF" % (fn.__name__, ms * 1e3, flops / ms / 1e9))
+    nbytes = 4.0 * (x.numel() + (x2.numel() if x2 is not None else 0) + y.numel())
+    res.append("io %.0f MB" % (nbytes / 1e6))
     print("%-26s %6.1f GFLOP | %s" % (name, flops / 1e9, " | ".join(res)), flush=True)

@@ -7,6 +7,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsprk.so")
 
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2          # SPRK_DT_*: precision of the MFMA operands (include/sprk.h)
+DT_FORCE = 0x100                           # SPRK_DT_FORCE: 16-bit kernel wherever it exists (tests), not only where faster
+DTYPES = {"f32": DT_F32, "fp32": DT_F32, "bf16": DT_BF16, "f16": DT_F16, "fp16": DT_F16,
+          "bf16!": DT_BF16 | DT_FORCE, "f16!": DT_F16 | DT_FORCE}
 
 c_f = ctypes.c_void_p      # device float*
 c_i = ctypes.c_int
@@ -17,7 +21,7 @@ c_sz = ctypes.c_size_t
 class ConvGeom(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("N", "C1", "C2", "Hin", "Win", "up1", "Cout", "Hout", "Wout",
-                 "KH", "KW", "stride", "dil", "pad_top", "pad_left")]
+                 "KH", "KW", "stride", "dil", "pad_top", "pad_left", "dtype")]
 
 
 class ConvEpilogue(ctypes.Structure):
@@ -31,6 +35,7 @@ _SIGS = {
     "sprk_version": (c_i, []),
     "sprk_launch_count": (ctypes.c_long, []),
     "sprk_wino_launch_count": (ctypes.c_long, []),
+    "sprk_conv16_launch_count": (ctypes.c_long, []),
     "sprk_set_naive": (None, [c_i]),
     "sprk_conv2d_fwd_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_fwd": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue), c_vp, c_sz, c_vp]),

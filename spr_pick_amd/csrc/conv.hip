@@ -17,6 +17,7 @@
 // maths: they serve strided backward-data (tiny detector layers) and as an on-device
 // cross-check (sprk_set_naive).
 #include "common.h"
+#include "conv16.h"
 #include "wino.h"
 
 #include <cstdlib>
@@ -25,6 +26,8 @@
 
 
 namespace {
+
+constexpr int kClass16 = 5;   // profiling class of the 16-bit-operand forward / backward-data kernel (conv16.hip)
 
 // ------------------------------------------------------------------------------------------
 // weight transform:  W[Cout][Cin][KHW]  ->  Wt[nblk][rows][ldw]   (rows = k in chunked order)
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
         chunk_mma<MT, NT, RB>(acc, ab, kaddr0 + (cke == a.CK ? 0 : a.R4 * 4), baddr0 + soff, bstep, nkq);
     }
 
-    store_acc<MT, NT>(a, acc, wave, lq, l15, nb, n0, oy0, ox0, lgT, TRm, TCm);
+#include "conv_epilogue.inc"
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1328,6 +1331,34 @@ sprk::WinoGeom wino_geom_bwd(const sprk_conv_geom *g) {
     return sprk::WinoGeom{g->N, g->Cout, 0, g->C1 + g->C2, g->Hout, g->Wout, g->Hin, g->Win, g->KH, g->KW, g->stride, g->dil,
                           (g->KH - 1) * g->dil - g->pad_top, (g->KW - 1) * g->dil - g->pad_left, g->up1, 0, 0};
 }
+// the 16-bit-operand kernels' view of a forward call / of a backward-data call (a forward-shaped convolution of gy
+// with the flipped, channel-transposed taps and mirrored padding)
+sprk::Conv16Call call16_fwd(const sprk_conv_geom *g, const sprk_conv_epilogue *ep) {
+    sprk::Conv16Call c{};
+    c.dtype = g->dtype; c.mode = 0;
+    c.N = g->N; c.C1 = g->C1; c.C2 = g->C2; c.Hin = g->Hin; c.Win = g->Win; c.Cout = g->Cout; c.Hout = g->Hout;
+    c.Wout = g->Wout; c.KH = g->KH; c.KW = g->KW; c.stride = g->stride; c.dil = g->dil; c.padT = g->pad_top;
+    c.padL = g->pad_left; c.up1 = g->up1;
+    if (ep) {
+        c.up2 = ep->up2; c.res = ep->res != nullptr; c.act = ep->act; c.bias = ep->bias; c.scale = ep->scale;
+        c.shift = ep->shift;
+    }
+    c.kclass = kClass16;
+    c.flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * g->KH * g->KW;
+    return c;
+}
+sprk::Conv16Call call16_bwd(const sprk_conv_geom *g) {
+    sprk::Conv16Call c{};
+    c.dtype = g->dtype; c.mode = 1;
+    c.N = g->N; c.C1 = g->Cout; c.C2 = 0; c.Hin = g->Hout; c.Win = g->Wout; c.Cout = g->C1 + g->C2; c.Hout = g->Hin;
+    c.Wout = g->Win; c.KH = g->KH; c.KW = g->KW; c.stride = g->stride; c.dil = g->dil;
+    c.padT = (g->KH - 1) * g->dil - g->pad_top; c.padL = (g->KW - 1) * g->dil - g->pad_left; c.up1 = g->up1;
+    c.act = SPRK_ACT_NONE;
+    c.kclass = kClass16;
+    c.flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * g->KH * g->KW;
+    return c;
+}
+
 size_t wino_ws_fwd(const sprk_conv_geom *g) {
     return sprk::wino_eligible(wino_geom_fwd(g, nullptr)) ? sprk::wino_ws_bytes(g->C1, g->C2, g->Cout) : 0;
 }
@@ -1348,7 +1379,9 @@ size_t sprk_conv2d_fwd_ws_bytes(const sprk_conv_geom *g) {
     FwdPlan p;
     if (!plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, g->pad_left, g->up1,
                   g->C2 > 0, g->Win, &p)) return 0;
-    return std::max(p.wsBytes, wino_ws_fwd(g));
+    size_t need = std::max(p.wsBytes, wino_ws_fwd(g));
+    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32) need = std::max(need, sprk::conv16_ws_bytes(call16_fwd(g, nullptr)));
+    return need;
 }
 
 int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, const sprk_conv_geom *g,
@@ -1365,6 +1398,10 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
         const long total = (long)g->N * g->Cout * g->Hout * g->Wout;
         hipLaunchKernelGGL(conv_fwd_direct_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, s, a);
         return sprk::check_launch("conv_fwd_direct");
+    }
+    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !sprk::g_naive) {
+        const sprk::Conv16Call c16 = call16_fwd(g, ep);
+        if (sprk::conv16_eligible(c16)) return sprk::conv16_run(c16, x, x2, w, y, ws, ws_bytes, s);
     }
     if (sprk::wino_eligible(wino_geom_fwd(g, ep)) && !ep->up2 && !ep->res) {
         const size_t need = sprk::wino_ws_bytes(g->C1, g->C2, g->Cout);
@@ -1415,7 +1452,9 @@ size_t sprk_conv2d_bwd_data_ws_bytes(const sprk_conv_geom *g) {
     FwdPlan p;
     if (!plan_fwd(g->N, g->Cout, g->C1 + g->C2, g->Hin, g->Win, g->KH, g->KW, 1, g->dil, (g->KW - 1) * g->dil - g->pad_left, 0, 0,
                   g->Wout, &p)) return 0;
-    return std::max(p.wsBytes, wino_ws_bwd(g));
+    size_t need = std::max(p.wsBytes, wino_ws_bwd(g));
+    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32) need = std::max(need, sprk::conv16_ws_bytes(call16_bwd(g)));
+    return need;
 }
 
 int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk_conv_geom *g, void *ws,
@@ -1432,6 +1471,10 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
         return sprk::check_launch("conv_bwd_data_direct");
     }
     // gin = correlation of gy with the flipped, channel-transposed kernel
+    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !sprk::g_naive) {
+        const sprk::Conv16Call c16 = call16_bwd(g);
+        if (sprk::conv16_eligible(c16)) return sprk::conv16_run(c16, gy, nullptr, w, gin, ws, ws_bytes, s);
+    }
     if (sprk::wino_eligible(wino_geom_bwd(g))) {
         const size_t need = sprk::wino_ws_bytes(g->Cout, 0, Cin);
         if (ws_bytes < need || !ws) {

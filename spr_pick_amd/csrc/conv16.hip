@@ -1,0 +1,823 @@
+// 16-bit-operand convolutions of libsprk.so (gfx950 / MI355X): forward and backward-data of the U-Net layers on
+// v_mfma_f32_16x16x32_{bf16,f16} (BASELINE configs[4]: "fp16 MFMA conv").
+//
+// What is 16-bit and what is not.  Tensors stay fp32 in HBM (activations, gradients, master weights: the
+// reference's layout, checkpoints and optimiser are untouched); only the two MFMA operands are rounded to
+// bf16 / fp16 (round-to-nearest-even, v_cvt_pk_*), products are exact in fp32 and accumulated in fp32 by the
+// matrix core.  Per output the error is that of rounding each input once: |err| <= 2 u * sum|a_k w_k| with
+// u = 2^-8 (bf16) or 2^-11 (fp16), the unit roundoffs of 8 / 11 significant bits — the bound the parity tests use.
+//
+// Same implicit GEMM as conv.hip:  Out[pixel][n] += A[pixel][k] * Wt[k][n],  k = (tap, channel).
+//   * the input tile (with halo, zeros outside the image) is staged exactly as in conv_mfma_kernel: fp32, by
+//     buffer_load ... lds through the per-workgroup offset tables (conv_dev.h), double buffered;
+//   * a k-step is 32 deep: lane (pixel l&15, quarter lq = l>>4) supplies 8 consecutive k.  k is ordered in
+//     GROUPS of 8 channels at one tap, so a lane's 8 values are 8 channel planes at one (pixel + tap) position:
+//     8 ds_read_b32 (plane stride apart) + 4 v_cvt_pk — the conversion happens here, on the way into the matrix
+//     core;  the four quarters of a k-step take four consecutive groups (group -> (tap, channel group) through a
+//     small LDS table, so chunks of 8, 16, 32 channels and 1x1 / 3x3 taps all use the same loop);
+//   * weights are converted once per call by weight_transform16_kernel into [N-block][chunk][group][n][8] 16-bit
+//     slabs: the B operand of (group, n) is one 16-byte ds_read_b128, rows of 16 n are 256 B apart (conflict free);
+//   * a channel count of 8m + 1 (the raw image concatenated to 96 features; the 1-channel first layer) puts the
+//     odd channel in a group of its own whose other 7 slots carry zero weights and re-read the same plane.
+// Epilogue (bias / BN affine / activation / fused 2x upsampling store) is conv_dev.h's, shared with the fp32 kernel.
+#include "conv16.h"
+
+#include "conv_dev.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T>
+struct Op16;
+template <>
+struct Op16<__bf16> {
+    using v8 = bf16x8;
+    static __device__ __forceinline__ f32x4 mma(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct Op16<_Float16> {
+    using v8 = f16x8;
+    static __device__ __forceinline__ f32x4 mma(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+struct Conv16Args {
+    ConvArgs c;          // geometry / staging / epilogue block shared with the fp32 kernel (wT unused here)
+    const void *w16;     // [nblk][nchunks][G4][NT16][8] 16-bit
+    int G4;              // group slots per chunk (a multiple of 4, zero-weight padded)
+    int ngFull, ngLast;  // groups actually present in a full chunk / in the last chunk
+    int c8Full, c8Last;  // channel groups per tap: ceil(cke / 8)
+    int ckeLast;         // channels in the last chunk
+    int nchunks;
+    int diag;            // debug bits (SPRK_C16_DIAG): 1 no input DMA, 2 no weight DMA, 4 no MFMA loop, 8 no store
+};
+
+// ---- weights: fp32 [Cout][Cin][KHW] -> 16-bit slabs -------------------------------------------------------
+//   mode 0 (forward):        GEMM-k channel = cin,  n = cout, tap as is
+//   mode 1 (backward-data):  GEMM-k channel = cout, n = cin,  tap flipped
+template <typename T>
+__global__ void weight_transform16_kernel(const float *__restrict__ w, T *__restrict__ ws, int Cout, int Cin, int KHW,
+                                          int mode, int CK, int G4, int NT16, int nblk, int nchunks) {
+    const int Ck = mode == 0 ? Cin : Cout;
+    const int Nn = mode == 0 ? Cout : Cin;
+    const long total = (long)nblk * nchunks * G4 * NT16 * 8;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        long t = e;
+        const int j = (int)(t & 7);
+        t >>= 3;
+        const int nl = (int)(t % NT16);
+        t /= NT16;
+        const int G = (int)(t % G4);
+        t /= G4;
+        const int q = (int)(t % nchunks);
+        const int nb = (int)(t / nchunks);
+        const int cke = min(CK, Ck - q * CK), c8 = (cke + 7) >> 3;
+        const int n = nb * NT16 + nl;
+        float v = 0.f;
+        if (G < KHW * c8 && n < Nn) {
+            const int tap = G / c8, cg = G - tap * c8;
+            const int cl = cg * 8 + j;
+            if (cl < cke) {
+                const int ck = q * CK + cl;
+                v = mode == 0 ? w[((long)n * Cin + ck) * KHW + tap] : w[((long)ck * Cin + n) * KHW + (KHW - 1 - tap)];
+            }
+        }
+        ws[e] = (T)v;
+    }
+}
+
+// ---- one staged chunk: nks k-steps of 32 ---------------------------------------------------------------------
+//   abase[r]: LDS byte address of this lane's pixel (row base r) at plane 0, tap 0 of the stage
+//   gaddr:    LDS byte address of gtab[lq] = {byte offset of the group's first plane + tap, plane stride}
+//   baddr:    LDS byte address of w16[group lq][n = l15]
+template <typename T, int MT, int NT, int RB>
+__device__ __forceinline__ void chunk_mma16(f32x4 (&acc)[MT][NT], const int (&abase)[RB], int gaddr, int baddr,
+                                            int bstep, int nks) {
+    using V8 = typename Op16<T>::v8;
+    constexpr int MPR = MT / RB;
+    typedef const __attribute__((address_space(3))) V8 *lds_v8p;
+    for (int ks = 0; ks < nks; ++ks) {
+        const int goff = lds_i(gaddr)[ks * 8], gstr = lds_i(gaddr)[ks * 8 + 1];
+        V8 av[MT];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            int ad = abase[r] + goff;
+            float f[MPR][8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                lds_cfp ap = lds_f(ad);
+#pragma unroll
+                for (int t = 0; t < MPR; ++t) f[t][j] = ap[16 * t];
+                ad += gstr;
+            }
+#pragma unroll
+            for (int t = 0; t < MPR; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[r * MPR + t][j] = (T)f[t][j];
+        }
+        V8 bv[NT];
+        const int bb = baddr + ks * bstep;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(bb + nt * 256);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Op16<T>::mma(av[mt], bv[nt], acc[mt][nt]);
+    }
+}
+
+template <typename T, int MT, int NT, int RB>
+__global__ __launch_bounds__(kBlock, 2) void conv16_mfma_kernel(const Conv16Args k) {
+    const ConvArgs &a = k.c;
+    // LDS: gtab[2][G4] {off, stride} (full chunk | last chunk) | xtab1 | xtab2 | stage 0: input fp32 [CK*cplane],
+    //      weights [G4][NT16][8] 16-bit | stage 1: ...
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NT16 = NT * 16;
+    const int wFloats = k.G4 * NT16 * 4;                  // 16 bytes per (group, n) = 4 floats
+    const int stageFloats = a.CK * a.cplane + wFloats;
+    int *gtab = reinterpret_cast<int *>(smem);
+    int *xtab1 = gtab + 4 * k.G4;
+    int *xtab2 = xtab1 + a.nG1 * 64;
+    float *stage_base = smem + 4 * k.G4 + (a.nG1 + a.nG2) * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    constexpr int TM = 64 * MT;
+    const int lgT = a.lgTC + a.lgTR;
+    const int NI = TM >> lgT;
+    int bid = blockIdx.x;
+    if (a.xcdRemap) {   // contiguous runs of tiles per XCD (vertically adjacent tiles share halo rows in its L2)
+        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    const int tx = bid % a.tilesX;
+    bid /= a.tilesX;
+    const int ty = bid % a.tilesY;
+    const int ig = bid / a.tilesY;
+    const int nb = blockIdx.y;
+    const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
+    const int iy0 = oy0 - a.padT, ix0 = ox0 - a.padL;      // stride 1
+    const int Cin = a.C1 + a.C2;
+    const int TCm = (1 << a.lgTC) - 1, TRm = (1 << a.lgTR) - 1;
+    const int lw = wave;
+
+    int abase[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int p = (wave * MT + r * (MT / RB)) * 16 + l15;
+        const int il = p >> lgT, rr = (p >> a.lgTC) & TRm, c = p & TCm;
+        abase[r] = ((il * a.inRows + rr) * a.pitch + c + a.colOff) * 4;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // group table: slot G of a chunk -> {byte offset of (first plane of the channel group, tap), plane stride}.
+    // A one-channel group (cke = 8m + 1) re-reads its plane 8 times (stride 0; slots 1..7 carry zero weights), and so
+    // do the padding slots behind the last group (all weights zero): every address read is inside the staged image.
+    for (int idx = tid; idx < 2 * k.G4; idx += kBlock) {
+        const int which = idx >= k.G4, G = idx - which * k.G4;
+        const int ng = which ? k.ngLast : k.ngFull, c8 = which ? k.c8Last : k.c8Full;
+        const int cke = which ? k.ckeLast : a.CK;
+        int off = 0, str = 0;
+        if (G < ng) {
+            const int tap = G / c8, cg = G - tap * c8;
+            const int ky = tap / a.KW, kx = tap - ky * a.KW;
+            off = (cg * 8 * a.cplane + ky * a.pitch + kx) * 4;
+            str = (cke - cg * 8 >= 8) ? a.cplane * 4 : 0;
+        }
+        gtab[2 * idx] = off;
+        gtab[2 * idx + 1] = str;
+    }
+    const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal, 4};
+    {
+        const int ixa = ix0 - a.colOff;
+        if (a.nG1)
+            build_xtab(xtab1, a.nG1, a.vec1, 0, a.W1, (long)a.C1 * a.H1 * a.W1, a.N, a.Hin, a.Win, pg, n0, iy0, ixa, tid,
+                       kBlock);
+        if (a.nG2)
+            build_xtab(xtab2, a.nG2, a.vec2, 0, a.Win, (long)a.C2 * a.Hin * a.Win, a.N, a.Hin, a.Win, pg, n0, iy0, ixa,
+                       tid, kBlock);
+    }
+    const float *wslab = reinterpret_cast<const float *>(k.w16) + (long)nb * k.nchunks * wFloats;
+
+    auto issue = [&](int c0, int b) {
+        const int cke = min(a.CK, Cin - c0);
+        float *in_lds = stage_base + b * stageFloats;
+        float *w_lds = in_lds + a.CK * a.cplane;
+        const int n1 = max(0, min(c0 + cke, a.C1) - c0);   // channels of this chunk taken from x
+        if (n1 > 0 && !(k.diag & 1)) {
+            const int cs1 = a.H1 * a.W1;
+            stage_planes_buf<4>(in_lds, make_rsrc(a.x + ((long)n0 * a.C1 + c0) * cs1), cs1 * 4, n1, xtab1, a.nG1, a.vec1,
+                                a.cplane, lw, lane);
+        }
+        if (n1 < cke && !(k.diag & 1)) {
+            const int cs2 = a.Hin * a.Win;
+            const int cb = max(c0, a.C1) - a.C1;
+            stage_planes_buf<4>(in_lds + n1 * a.cplane, make_rsrc(a.x2 + ((long)n0 * a.C2 + cb) * cs2), cs2 * 4, cke - n1,
+                                xtab2, a.nG2, a.vec2, a.cplane, lw, lane);
+        }
+        const rsrc_t wr = make_rsrc(wslab + (long)(c0 / a.CK) * wFloats);
+        const int total4 = wFloats >> 2;                    // 16-byte pieces of the chunk's weight slab
+        const int wv = lane * 16, room = total4 - lane;
+        if (!(k.diag & 2))
+            for (int gi = lw; gi * 64 < total4; gi += 4)
+                if (gi * 64 < room) bdma16(wr, wv, gi * 1024, w_lds + gi * 256);
+    };
+
+    __syncthreads();   // tables visible
+    issue(0, 0);
+    const int baddr0 = lds_addr(stage_base + a.CK * a.cplane) + (lq * NT16 + l15) * 16;
+    const int gaddr0 = lds_addr(gtab + 2 * lq);
+    const int abyte0 = lds_addr(stage_base);
+    constexpr int bstep = 4 * NT16 * 16;
+    int ci = 0;
+    for (int c0 = 0; c0 < Cin; c0 += a.CK, ++ci) {
+        __syncthreads();   // this chunk's DMA has landed for every wave; nobody reads the other stage any more
+        if (c0 + a.CK < Cin) issue(c0 + a.CK, (ci + 1) & 1);
+        const bool lastc = c0 + a.CK >= Cin;
+        const int ng = lastc ? k.ngLast : k.ngFull;
+        const int soff = (ci & 1) * stageFloats * 4;
+        int ab[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) ab[r] = abyte0 + soff + abase[r];
+        if (!(k.diag & 4))
+            chunk_mma16<T, MT, NT, RB>(acc, ab, gaddr0 + (lastc ? k.G4 * 8 : 0), baddr0 + soff, bstep, (ng + 3) >> 2);
+    }
+    if (k.diag & 8) return;
+#include "conv_epilogue.inc"
+}
+
+// =====================================================================================================================
+// conv16_tile_kernel: the 3x3 layers.  The kernel above keeps conv_mfma_kernel's staging (fp32 tiles by LDS-DMA, 8
+// channels per barrier) and is bound by it: with 16x less matrix time per byte the DMA issue, the per-chunk barrier and
+// the 8 ds_read_b32 + 4 conversions per operand dominate (measured on 96->96 at 128x64^2: 420 us with the DMA switched
+// off, 150 us for the data movement alone, 570 us together — no overlap).  This kernel is built for the 16-bit
+// compute/byte ratio instead:
+//   * 512-thread workgroups (8 waves, 2 per SIMD), one per CU, 512 output pixels x 16*NT output channels: half the
+//     weight re-staging per pixel and a smaller halo share than 256-pixel tiles;
+//   * the input tile of the NEXT 16-channel chunk is fetched HBM -> registers (buffer_load_dword, 24 in flight per
+//     lane, zeros outside the image by the buffer range check) while the matrix cores work on the current chunk, then
+//     converted ONCE (v_cvt_pk) and written to LDS channel-innermost: [8-channel group][halo pixel][8 x 16 bit], so an
+//     A operand (pixel, 8 channels at one tap) is ONE ds_read_b128 and every tap re-uses the converted tile;
+//   * weights as above (16-bit slabs [group][n][8], one ds_read_b128 per B operand) by LDS-DMA, double buffered;
+//   * a k-step's four lane quarters take groups (tap t, channels 0-7), (t, 8-15), (t+1, 0-7), (t+1, 8-15): the two
+//     quarters that share an LDS service group differ by a whole channel-group plane (a multiple of 256 B), so the
+//     reads are conflict free;  one barrier per 16 channels x 9 taps = 5 k-steps x 24 MFMAs per wave.
+// Any channel count works (missing channels of the last chunk are zero registers and zero weights).
+// =====================================================================================================================
+struct Tile16Args {
+    ConvArgs c;          // N, C1, C2, Hin, Win, Cout, Hout, Wout, pads, epilogue, lgTC, lgTR, tilesX, tilesY (store_acc)
+    const void *w16;     // [nblk][nchunks][G4][NT16][8]
+    int G4, nchunks, ngFull, ngLast, c8Last;
+    int PX, PXP, inRows, inCols;   // halo pixels of a tile (all its images), padded to 16; halo rows / cols per image
+    int diag;
+};
+
+constexpr int kTileThreads = 512;
+constexpr int kTileCK = 16;
+
+template <typename T, int NT>
+__global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16Args k) {
+    using V8 = typename Op16<T>::v8;
+    typedef const __attribute__((address_space(3))) V8 *lds_v8p;
+    typedef __attribute__((address_space(3))) V8 *lds_v8w;
+    const ConvArgs &a = k.c;
+    constexpr int NT16 = NT * 16, MT = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int *gtab = reinterpret_cast<int *>(smem);                 // [2][G4] byte offsets (full chunk | last chunk)
+    const int inBytes = 2 * k.PXP * 16, wBytes = k.G4 * NT16 * 16, stageBytes = inBytes + wBytes;
+    const int stage0 = lds_addr(smem) + 256;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int lgT = a.lgTC + a.lgTR;
+    const int NI = 512 >> lgT;
+    int bid = blockIdx.x;
+    {   // contiguous runs of tiles per XCD
+        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    const int tx = bid % a.tilesX;
+    bid /= a.tilesX;
+    const int ty = bid % a.tilesY;
+    const int ig = bid / a.tilesY;
+    const int nb = blockIdx.y;
+    const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
+    const int iy0 = oy0 - a.padT, ix0 = ox0 - a.padL;
+    const int Cin = a.C1 + a.C2, HW = a.Hin * a.Win;
+    const int TCm = (1 << a.lgTC) - 1, TRm = (1 << a.lgTR) - 1;
+
+    // ---- this thread's share of the tile fetch: up to 3 (channel group, halo pixel) items ----------------------
+    // item i = tid + 512 r: channel group cg = i / P64 (wave-uniform: P64 is a multiple of 64), halo pixel i % P64
+    const int P64 = (k.PX + 63) & ~63;
+    const int imgPix = k.inRows * k.inCols;
+    int voff1[3], voff2[3], wofs[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int i = tid + r * kTileThreads;
+        const int cg = i / P64, px = i - cg * P64;
+        voff1[r] = voff2[r] = (int)0x80000000;     // beyond the buffer range: the load returns 0
+        wofs[r] = -1;
+        if (cg < 2 && px < k.PX) {
+            const int il = px / imgPix, rem = px - il * imgPix;
+            const int rr = rem / k.inCols, cc = rem - rr * k.inCols;
+            const int n = n0 + il, iy = iy0 + rr, ix = ix0 + cc;
+            wofs[r] = (cg * k.PXP + px) * 16;
+            if (n < a.N && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win) {
+                const int pix = iy * a.Win + ix;
+                voff1[r] = (il * a.C1 * HW + pix) * 4;
+                voff2[r] = (il * a.C2 * HW + pix) * 4;
+            }
+        }
+    }
+    float f[3][8];
+    auto fetch = [&](int c0) {      // channels c0 .. c0+15 of the concatenated input -> registers
+        // buffer bases at the chunk's first channel of each source: the per-channel scalar offset stays small
+        // whatever the plane size (4096^2 planes: 64 MB per channel)
+        const int b1 = min(c0, a.C1), b2 = max(c0 - a.C1, 0);
+        const rsrc_t r1 = make_rsrc(a.x + ((long)n0 * a.C1 + b1) * HW);
+        const rsrc_t r2 = make_rsrc(a.C2 ? a.x2 + ((long)n0 * a.C2 + b2) * HW : a.x);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int cg = __builtin_amdgcn_readfirstlane((tid + r * kTileThreads) / P64);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ch = c0 + cg * 8 + j;     // wave-uniform
+                unsigned v = 0;
+                if (cg < 2 && ch < Cin && !(k.diag & 1)) {
+                    if (ch < a.C1)
+                        v = __builtin_amdgcn_raw_buffer_load_b32(r1, voff1[r], (ch - b1) * HW * 4, 0);
+                    else
+                        v = __builtin_amdgcn_raw_buffer_load_b32(r2, voff2[r], (ch - a.C1 - b2) * HW * 4, 0);
+                }
+                f[r][j] = __builtin_bit_cast(float, v);
+            }
+        }
+    };
+    auto convert_store = [&](int b) {   // registers -> 16 bit -> LDS stage b, [group][pixel][8]
+        const int base = stage0 + b * stageBytes;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            V8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (T)f[r][j];
+            if (wofs[r] >= 0) *(lds_v8w)(__SIZE_TYPE__)(unsigned)(base + wofs[r]) = v;
+        }
+    };
+    const float *wslab = reinterpret_cast<const float *>(k.w16) + (long)nb * k.nchunks * (wBytes >> 2);
+    auto weights = [&](int chunk, int b) {   // the chunk's weight slab -> LDS stage b (LDS-DMA, 1 KB per wave instruction)
+        if (k.diag & 2) return;
+        const rsrc_t wr = make_rsrc(wslab + (long)chunk * (wBytes >> 2));
+        float *w_lds = smem + 64 + ((b * stageBytes + inBytes) >> 2);
+        const int total16 = wBytes >> 4;
+        const int wv = lane * 16, room = total16 - lane;
+        for (int gi = wave; gi * 64 < total16; gi += 8)
+            if (gi * 64 < room) bdma16(wr, wv, gi * 1024, w_lds + gi * 256);
+    };
+
+    // group table: slot G -> byte offset of (channel group, tap) inside a stage's input image; padding slots point at
+    // offset 0 (their weights are zero)
+    for (int idx = tid; idx < 2 * k.G4; idx += kTileThreads) {
+        const int which = idx >= k.G4, G = idx - which * k.G4;
+        const int ng = which ? k.ngLast : k.ngFull, c8 = which ? k.c8Last : 2;
+        int off = 0;
+        if (G < ng) {
+            const int tap = G / c8, cg = G - tap * c8;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            off = (cg * k.PXP + ky * k.inCols + kx) * 16;
+        }
+        gtab[idx] = off;
+    }
+    // this lane's four A-operand bases: output pixel (wave, mt, l15) -> its halo pixel at tap (0,0)
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int p = (wave * MT + mt) * 16 + l15;
+        const int il = p >> lgT, rr = (p >> a.lgTC) & TRm, c = p & TCm;
+        abase[mt] = ((il * k.inRows + rr) * k.inCols + c) * 16;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    weights(0, 0);
+    convert_store(0);
+    const int baddr0 = stage0 + inBytes + (lq * NT16 + l15) * 16;
+    constexpr int bstep = 4 * NT16 * 16;
+    for (int ci = 0; ci < k.nchunks; ++ci) {
+        __syncthreads();     // stage ci&1 complete (every wave's ds_writes and DMA); the other stage is free again
+        const bool more = ci + 1 < k.nchunks;
+        if (more) {
+            fetch((ci + 1) * kTileCK);          // in flight while this chunk is multiplied
+            weights(ci + 1, (ci + 1) & 1);
+        }
+        if (!(k.diag & 4)) {
+            const bool lastc = !more;
+            const int nks = ((lastc ? k.ngLast : k.ngFull) + 3) >> 2;
+            const int sb = (ci & 1) * stageBytes;
+            const int gaddr = lds_addr(gtab + (lastc ? k.G4 : 0) + lq);
+            const int ain = stage0 + sb, bb0 = baddr0 + sb;
+            for (int ks = 0; ks < nks; ++ks) {
+                const int goff = lds_i(gaddr)[ks * 4] + ain;
+                V8 av[MT], bv[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(abase[mt] + goff);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(bb0 + ks * bstep + nt * 256);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Op16<T>::mma(av[mt], bv[nt], acc[mt][nt]);
+            }
+        }
+        if (more) convert_store((ci + 1) & 1);   // waits for the fetch (vmcnt), converts, writes the other stage
+    }
+    if (k.diag & 8) return;
+    // ---- epilogue: bias / affine / activation in registers, then through LDS so that global stores are whole rows ----
+    // The accumulator layout puts the 16 output CHANNELS of a tile on 16 lanes: stored directly, a wave instruction
+    // writes 64 B to each of 16 channel planes and the kernel is bound by store issue (measured: 88 of 187 us on
+    // 96->96 at 128x64^2).  Each wave transposes its own 64 pixels x 48 channels per pass in a private LDS region
+    // ([channel][64 pixels + 4 pad] floats, no workgroup barrier: a wave only reads what it wrote) and then stores
+    // 4 channel rows x 256 B per instruction.  Falls back to the shared epilogue for residual / unaligned outputs.
+    if (a.res || !a.vec4 || (a.Wout & 3)) {
+#include "conv_epilogue.inc"
+        return;
+    }
+    __syncthreads();                       // every wave is done with the stages: LDS is free
+    {
+        constexpr int ROWF = 68;           // floats per channel row in LDS (64 pixels + 4: conflict-free b128 accesses)
+        const int region = lds_addr(smem) + 256 + wave * (48 * ROWF * 4);
+        typedef __attribute__((address_space(3))) f32x4 *lds_f4w;
+        typedef const __attribute__((address_space(3))) f32x4 *lds_f4r;
+        // pixel part of the store address of this lane's readback chunk (4 consecutive pixels of the wave's 64)
+        const int chunk = lane & 15, rsub = lane >> 4;
+        const int p = wave * 64 + chunk * 4;
+        const int il = p >> lgT, pr = (p >> a.lgTC) & TRm, pc = p & TCm;
+        const int n = n0 + il, oy = oy0 + pr, ox = ox0 + pc;
+        const bool pok = n < a.N && oy < a.Hout && ox < a.Wout;
+        const long planeO = (long)a.Hout * a.Wout, planeY = a.up2 ? planeO * 4 : planeO;
+        const long W2 = 2L * a.Wout;
+        const long pixoff = (long)n * a.Cout * planeY + (a.up2 ? (long)(2 * oy) * W2 + 2 * ox : (long)oy * a.Wout + ox);
+#pragma unroll
+        for (int half = 0; half < NT / 3; ++half) {
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) {
+                const int nt = half * 3 + t3;
+                const int co = nb * NT16 + nt * 16 + l15;
+                float sc = 1.f, sh = 0.f;
+                if (co < a.Cout) {
+                    if (a.scale) {
+                        sc = a.scale[co];
+                        sh = a.shift[co];
+                    } else if (a.bias) {
+                        sh = a.bias[co];
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 v = acc[mt][nt];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j] * sc + sh, a.act);
+                    *(lds_f4w)(__SIZE_TYPE__)(unsigned)(region + ((t3 * 16 + l15) * ROWF + mt * 16 + lq * 4) * 4) = v;
+                }
+            }
+            // rows 4i .. 4i+3 of the 48: lane -> (row 4i + rsub, 16-byte chunk)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const int row = 4 * i + rsub;
+                const f32x4 v = *(lds_f4r)(__SIZE_TYPE__)(unsigned)(region + (row * ROWF + chunk * 4) * 4);
+                const int co = nb * NT16 + half * 48 + row;
+                if (pok && co < a.Cout) {
+                    float *q = a.y + pixoff + (long)co * planeY;
+                    if (a.up2) {
+                        const float4 lo = make_float4(v[0], v[0], v[1], v[1]), hi = make_float4(v[2], v[2], v[3], v[3]);
+                        *reinterpret_cast<float4 *>(q) = lo;
+                        *reinterpret_cast<float4 *>(q + 4) = hi;
+                        *reinterpret_cast<float4 *>(q + W2) = lo;
+                        *reinterpret_cast<float4 *>(q + W2 + 4) = hi;
+                    } else {
+                        *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+constexpr size_t kLdsBudget16 = 78 * 1024;   // two workgroups per CU
+
+struct Plan16 {
+    int MT, NT, lgTC, lgTR, tilesX, tilesY, imgGroups, nblkN, NI;
+    int CK, G4, nchunks;
+    int inRows, inCols, pitch, cplane, colOff;
+    int nG1, nG2;
+    size_t ldsBytes, wsBytes;
+};
+
+int pad_to_residue16(int raw, int residue) { return raw + ((residue - raw % 32) + 32) % 32; }
+
+bool plan16(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int padL, int hasC2, int WinSrc, Plan16 *p) {
+    using sprk::cdiv;
+    const int KHW = KH * KW;
+    if (!((KH == 3 && KW == 3) || (KH == 1 && KW == 1))) return false;
+    if (Ck % 8 > 1 || Nn < 33 || WinSrc % 4 != 0) return false;
+    if ((long)Ho * Wo < 256 || Wo % 16 != 0) return false;
+    const int ntile = cdiv(Nn, 16);
+    int NT = 6, best = 1 << 30;
+    for (int cand : {6, 4, 3}) {                      // instantiated channel-tile counts
+        const int cost = cdiv(ntile, cand) * (cand + 2);
+        if (cost < best) best = cost, NT = cand;
+    }
+    for (int MT : {4, 2}) {
+        const int TM = 64 * MT;
+        const int TC = std::min(std::min(sprk::pow2_ceil(Wo), 64), TM);
+        const int TR = std::min(TM / TC, sprk::pow2_ceil(Ho));
+        const int NI = TM / (TC * TR);
+        p->MT = MT; p->NT = NT; p->NI = NI;
+        p->lgTC = sprk::ilog2(TC); p->lgTR = sprk::ilog2(TR);
+        p->tilesX = cdiv(Wo, TC); p->tilesY = cdiv(Ho, TR);
+        p->imgGroups = cdiv(Nimg, NI);
+        p->nblkN = cdiv(ntile, NT);
+        p->inRows = TR + KH - 1;
+        p->inCols = TC + KW - 1;
+        p->colOff = (((-padL) % 4) + 4) % 4;
+        p->pitch = sprk::roundup(p->colOff + p->inCols, 4);
+        p->cplane = pad_to_residue16(NI * p->inRows * p->pitch, 16);
+        const long blocks = (long)p->imgGroups * p->tilesX * p->tilesY * p->nblkN;
+        if (MT == 4 && blocks < 512) continue;        // too few workgroups for 256 CUs x 2: smaller tiles
+        const int planeElems = NI * p->inRows * p->pitch;
+        p->nG1 = cdiv(planeElems, 256);
+        p->nG2 = hasC2 ? p->nG1 : 0;
+        if (p->nG1 > kMaxXG) continue;
+        // channels per chunk: a multiple of 8 (or all of them when fewer); 1x1 layers take 32 (one full k-step)
+        for (int CK : (KHW == 1 ? std::initializer_list<int>{32, 16, 8} : std::initializer_list<int>{16, 8})) {
+            const int ck = std::min(CK, sprk::roundup(Ck, 8));
+            const int G4 = sprk::roundup(KHW * cdiv(ck, 8), 4);
+            const size_t lds = (size_t)(4 * G4 + (p->nG1 + p->nG2) * 64) * 4 +
+                               2 * ((size_t)ck * p->cplane * 4 + (size_t)G4 * NT * 16 * 16);
+            if (lds > kLdsBudget16) continue;
+            p->CK = ck; p->G4 = G4; p->nchunks = cdiv(Ck, ck);
+            p->ldsBytes = lds;
+            p->wsBytes = (size_t)p->nblkN * p->nchunks * G4 * NT * 16 * 16;
+            return true;
+        }
+    }
+    return false;
+}
+
+template <typename T, int MT, int RB>
+int launch16_nt(const Conv16Args &k, const Plan16 &p, dim3 grid, hipStream_t s) {
+    auto go = [&](auto kernel) {
+        if (p.ldsBytes > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)p.ldsBytes) != hipSuccess) {
+            sprk::set_error("conv16: cannot reserve %zu bytes of LDS", p.ldsBytes);
+            return (int)SPRK_ELAUNCH;
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(kBlock), p.ldsBytes, s, k);
+        return (int)SPRK_OK;
+    };
+    switch (p.NT) {
+        case 3: return go(conv16_mfma_kernel<T, MT, 3, RB>);
+        case 4: return go(conv16_mfma_kernel<T, MT, 4, RB>);
+        default: return go(conv16_mfma_kernel<T, MT, 6, RB>);
+    }
+}
+
+template <typename T>
+int launch16(const Conv16Args &k, const Plan16 &p, hipStream_t s) {
+    dim3 grid(p.imgGroups * p.tilesX * p.tilesY, p.nblkN);
+    const int rows = std::max(1, (p.MT * 16) >> p.lgTC);   // tile rows a wave's pixel tiles span
+    if (p.MT == 4)
+        return rows == 1 ? launch16_nt<T, 4, 1>(k, p, grid, s)
+                         : rows == 2 ? launch16_nt<T, 4, 2>(k, p, grid, s) : launch16_nt<T, 4, 4>(k, p, grid, s);
+    return rows == 1 ? launch16_nt<T, 2, 1>(k, p, grid, s) : launch16_nt<T, 2, 2>(k, p, grid, s);
+}
+
+std::atomic<long> g_conv16_launches{0};
+
+// ---- 3x3 layers: conv16_tile_kernel -----------------------------------------------------------------------------
+struct PlanT {
+    int NT, lgTC, lgTR, tilesX, tilesY, imgGroups, nblkN, NI;
+    int G4, nchunks, PX, PXP, inRows, inCols;
+    size_t ldsBytes, wsBytes;
+};
+
+bool plan_tile(int Nimg, int Ck, int Nn, int Ho, int Wo, PlanT *p) {
+    using sprk::cdiv;
+    if (Nn < 33 || (long)Ho * Wo < 256 || Wo % 4 != 0) return false;
+    const int ntile = cdiv(Nn, 16);
+    p->NT = (ntile <= 3) ? 3 : 6;
+    const int TC = std::min(sprk::pow2_ceil(Wo), 64);
+    const int TR = std::min(512 / TC, sprk::pow2_ceil(Ho));
+    const int NI = 512 / (TC * TR);
+    p->NI = NI;
+    p->lgTC = sprk::ilog2(TC); p->lgTR = sprk::ilog2(TR);
+    p->tilesX = cdiv(Wo, TC); p->tilesY = cdiv(Ho, TR);
+    p->imgGroups = cdiv(Nimg, NI);
+    p->nblkN = cdiv(ntile, p->NT);
+    if ((long)p->imgGroups * p->tilesX * p->tilesY * p->nblkN < 128) return false;   // too few workgroups: fp32 path
+    p->inRows = TR + 2; p->inCols = TC + 2;
+    p->PX = NI * p->inRows * p->inCols;
+    if (p->PX > 768) return false;
+    p->PXP = sprk::roundup(p->PX, 16);
+    p->G4 = 20;                                   // 9 taps x 2 channel groups, padded to whole k-steps
+    p->nchunks = cdiv(Ck, kTileCK);
+    p->ldsBytes = 256 + std::max(2 * ((size_t)2 * p->PXP * 16 + (size_t)p->G4 * p->NT * 16 * 16),
+                                 (size_t)8 * 48 * 68 * 4);      // two stages | the epilogue's 8 transpose regions
+    p->wsBytes = (size_t)p->nblkN * p->nchunks * p->G4 * p->NT * 16 * 16;
+    return true;
+}
+
+template <typename T>
+int launch_tile(const Tile16Args &k, const PlanT &p, hipStream_t s) {
+    dim3 grid(p.imgGroups * p.tilesX * p.tilesY, p.nblkN);
+    auto go = [&](auto kernel) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)p.ldsBytes) != hipSuccess) {
+            sprk::set_error("conv16: cannot reserve %zu bytes of LDS", p.ldsBytes);
+            return (int)SPRK_ELAUNCH;
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(kTileThreads), p.ldsBytes, s, k);
+        return (int)SPRK_OK;
+    };
+    return p.NT == 3 ? go(conv16_tile_kernel<T, 3>) : go(conv16_tile_kernel<T, 6>);
+}
+
+}  // namespace
+
+namespace sprk {
+
+// which 16-bit kernel (if any) takes this call: 2 = conv16_tile_kernel (3x3), 1 = conv16_mfma_kernel (1x1), 0 = none
+static int plan_of(const Conv16Call &c, Plan16 *p, PlanT *pt) {
+    const int dt = c.dtype & SPRK_DT_MASK;
+    if (dt != SPRK_DT_BF16 && dt != SPRK_DT_F16) return 0;
+    static const int on = getenv("SPRK_CONV16") ? atoi(getenv("SPRK_CONV16")) : 1;   // debug: 0 = always fp32
+    if (!on) return 0;
+    if (c.stride != 1 || c.dil != 1 || c.up1 || c.res) return 0;
+    if (c.Hout != c.Hin || c.Wout != c.Win) return 0;                 // same-size layers (U-Net body)
+    if (c.padL < 0 || c.padL > 4 || c.padT < 0) return 0;
+    if (c.KH == 3 && c.KW == 3) {
+        static const int tile_on = getenv("SPRK_CONV16_TILE") ? atoi(getenv("SPRK_CONV16_TILE")) : 1;   // debug
+        if (tile_on && plan_tile(c.N, c.C1 + c.C2, c.Cout, c.Hout, c.Wout, pt)) {
+            // 32-bit byte offsets: an image group's span and 16 channel planes
+            const long HW = (long)c.Hin * c.Win, cmax = std::max(c.C1, c.C2);
+            if (((pt->NI - 1) * cmax + 1) * HW * 4 < (1L << 31) && 16 * HW * 4 < (1L << 31)) return 2;
+        }
+    }
+    // Where the fp32 Winograd kernel is the faster one (measured on MI355X, scratch/convbench.py): on the wide 3x3
+    // layers at 64x64 and up the 256-pixel-tile kernel is bound by moving fp32 tiles through LDS-DMA (96->96 at
+    // 128x64^2: 455 us fp32 Winograd, 570 us here).  Without SPRK_DT_FORCE those layers stay fp32.
+    if (!(c.dtype & SPRK_DT_FORCE) && c.KH == 3 && c.Cout > 48 && (long)c.Hout * c.Wout >= 4096) return 0;
+    // table offsets are 32-bit byte offsets inside one image group; a chunk's channel offset below 2^32
+    if (!plan16(c.N, c.C1 + c.C2, c.Cout, c.Hout, c.Wout, c.KH, c.KW, c.padL, c.C2 > 0, c.Win, p)) return 0;
+    const long NIm1 = p->NI - 1;
+    if ((NIm1 * c.C1 + 1) * c.Hin * c.Win >= (1L << 29) || (long)p->CK * c.Hin * c.Win >= (1L << 29)) return 0;
+    if (c.C2 && ((NIm1 * c.C2 + 1) * c.Hin * c.Win >= (1L << 29))) return 0;
+    return 1;
+}
+
+bool conv16_eligible(const Conv16Call &c) {
+    Plan16 p;
+    PlanT pt;
+    return plan_of(c, &p, &pt) != 0;
+}
+
+size_t conv16_ws_bytes(const Conv16Call &c) {
+    Plan16 p;
+    PlanT pt;
+    const int which = plan_of(c, &p, &pt);
+    return which == 2 ? pt.wsBytes + 512 : which == 1 ? p.wsBytes + 512 : 0;
+}
+
+long conv16_launches() { return g_conv16_launches.load(); }
+
+static int run_tile(const Conv16Call &c, const PlanT &p, const float *x, const float *x2, const float *w, float *y,
+                    void *ws, size_t ws_bytes, hipStream_t s) {
+    if (ws_bytes < p.wsBytes || !ws) {
+        set_error("conv16: workspace too small (%zu < %zu)", ws_bytes, p.wsBytes);
+        return SPRK_EWORKSPACE;
+    }
+    if ((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)y | (uintptr_t)ws) & 15) != 0) {
+        set_error("conv16: tensors must be 16-byte aligned");
+        return SPRK_EINVAL;
+    }
+    const int Cin = c.C1 + c.C2;
+    const int dt = c.dtype & SPRK_DT_MASK;
+    const long total = (long)p.nblkN * p.nchunks * p.G4 * p.NT * 16 * 8;
+    const int wCout = c.mode == 0 ? c.Cout : Cin, wCin = c.mode == 0 ? Cin : c.Cout;
+    if (dt == SPRK_DT_BF16)
+        hipLaunchKernelGGL(weight_transform16_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (__bf16 *)ws,
+                           wCout, wCin, 9, c.mode, kTileCK, p.G4, p.NT * 16, p.nblkN, p.nchunks);
+    else
+        hipLaunchKernelGGL(weight_transform16_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (_Float16 *)ws,
+                           wCout, wCin, 9, c.mode, kTileCK, p.G4, p.NT * 16, p.nblkN, p.nchunks);
+    if (int rc = check_launch("weight_transform16")) return rc;
+    Tile16Args k{};
+    ConvArgs &a = k.c;
+    a.x = x; a.x2 = x2; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift; a.res = nullptr; a.y = y;
+    a.N = c.N; a.C1 = c.C1; a.C2 = c.C2; a.Hin = c.Hin; a.Win = c.Win; a.H1 = c.Hin; a.W1 = c.Win;
+    a.Cout = c.Cout; a.Hout = c.Hout; a.Wout = c.Wout; a.KH = 3; a.KW = 3; a.stride = 1; a.dil = 1;
+    a.padT = c.padT; a.padL = c.padL; a.act = c.act;
+    a.lgTC = p.lgTC; a.lgTR = p.lgTR; a.tilesX = p.tilesX; a.tilesY = p.tilesY;
+    a.vec4 = 1; a.up2 = c.up2;
+    k.w16 = ws;
+    k.G4 = p.G4; k.nchunks = p.nchunks;
+    k.ngFull = 18;
+    const int ckeLast = Cin - (p.nchunks - 1) * kTileCK;
+    k.c8Last = cdiv(ckeLast, 8);
+    k.ngLast = 9 * k.c8Last;
+    k.PX = p.PX; k.PXP = p.PXP; k.inRows = p.inRows; k.inCols = p.inCols;
+    static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
+    k.diag = diag;
+    prof_begin(c.kclass, c.flops, s);
+    const int rc = dt == SPRK_DT_BF16 ? launch_tile<__bf16>(k, p, s) : launch_tile<_Float16>(k, p, s);
+    if (rc) return rc;
+    prof_end(c.kclass, s);
+    g_conv16_launches.fetch_add(1, std::memory_order_relaxed);
+    return check_launch("conv16_tile");
+}
+
+int conv16_run(const Conv16Call &c, const float *x, const float *x2, const float *w, float *y, void *ws, size_t ws_bytes,
+               hipStream_t s) {
+    Plan16 p;
+    PlanT pt;
+    const int which = plan_of(c, &p, &pt);
+    if (which == 2) return run_tile(c, pt, x, x2, w, y, ws, ws_bytes, s);
+    if (which == 0) {
+        set_error("conv16: geometry not eligible");
+        return SPRK_EINVAL;
+    }
+    if (ws_bytes < p.wsBytes || !ws) {
+        set_error("conv16: workspace too small (%zu < %zu)", ws_bytes, p.wsBytes);
+        return SPRK_EWORKSPACE;
+    }
+    if ((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)y | (uintptr_t)ws) & 15) != 0) {
+        set_error("conv16: tensors must be 16-byte aligned");
+        return SPRK_EINVAL;
+    }
+    const int Cin = c.C1 + c.C2, KHW = c.KH * c.KW;
+    // GEMM view: forward k = input channels (w[cout][cin]); backward-data k = the forward layer's output channels
+    // (x = gy), n = its input channels, taps flipped.  c.* describe the GEMM (C1 + C2 = k channels, Cout = n).
+    const long total = (long)p.nblkN * p.nchunks * p.G4 * p.NT * 16 * 8;
+    const int wCout = c.mode == 0 ? c.Cout : Cin, wCin = c.mode == 0 ? Cin : c.Cout;
+    const int dt = c.dtype & SPRK_DT_MASK;
+    if (dt == SPRK_DT_BF16)
+        hipLaunchKernelGGL(weight_transform16_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (__bf16 *)ws,
+                           wCout, wCin, KHW, c.mode, p.CK, p.G4, p.NT * 16, p.nblkN, p.nchunks);
+    else
+        hipLaunchKernelGGL(weight_transform16_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (_Float16 *)ws,
+                           wCout, wCin, KHW, c.mode, p.CK, p.G4, p.NT * 16, p.nblkN, p.nchunks);
+    if (int rc = check_launch("weight_transform16")) return rc;
+
+    Conv16Args k{};
+    ConvArgs &a = k.c;
+    a.x = x; a.x2 = x2; a.wT = nullptr; a.zeros = nullptr; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift;
+    a.res = nullptr; a.y = y;
+    a.N = c.N; a.C1 = c.C1; a.C2 = c.C2; a.Hin = c.Hin; a.Win = c.Win; a.up1 = 0; a.H1 = c.Hin; a.W1 = c.Win;
+    a.Cout = c.Cout; a.Hout = c.Hout; a.Wout = c.Wout; a.KH = c.KH; a.KW = c.KW; a.stride = 1; a.dil = 1;
+    a.padT = c.padT; a.padL = c.padL; a.act = c.act;
+    a.lgTC = p.lgTC; a.lgTR = p.lgTR; a.tilesX = p.tilesX; a.tilesY = p.tilesY;
+    a.CK = p.CK; a.R4 = 0; a.rows = 0;
+    a.inRows = p.inRows; a.inCols = p.inCols; a.pitch = p.pitch; a.cplane = p.cplane; a.colOff = p.colOff; a.ldw = 0;
+    a.resH = a.resW = a.resOff = 0;
+    a.vec1 = 1; a.vec2 = c.C2 ? 1 : 0; a.vec4 = (c.Wout % 4 == 0) ? 1 : 0; a.up2 = c.up2; a.deal = 1; a.xcdRemap = 1;
+    a.xtab = 1; a.nG1 = p.nG1; a.nG2 = p.nG2;
+    a.invImg = 1.0f / (float)(p.inRows * p.pitch);
+    a.invPitch = 1.0f / (float)p.pitch;
+    k.w16 = ws;
+    k.G4 = p.G4;
+    k.nchunks = p.nchunks;
+    k.c8Full = cdiv(p.CK, 8);
+    k.ngFull = KHW * k.c8Full;
+    k.ckeLast = Cin - (p.nchunks - 1) * p.CK;
+    k.c8Last = cdiv(k.ckeLast, 8);
+    k.ngLast = KHW * k.c8Last;
+    static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
+    k.diag = diag;
+    prof_begin(c.kclass, c.flops, s);
+    const int rc = dt == SPRK_DT_BF16 ? launch16<__bf16>(k, p, s) : launch16<_Float16>(k, p, s);
+    if (rc) return rc;
+    prof_end(c.kclass, s);
+    g_conv16_launches.fetch_add(1, std::memory_order_relaxed);
+    return check_launch("conv16_mfma");
+}
+
+}  // namespace sprk

@@ -214,71 +214,4 @@ __device__ __forceinline__ void store_tile(const ConvArgs &a, const f32x4 c, int
     }
 }
 
-// Epilogue of a workgroup's accumulators (MT pixel tiles x NT channel tiles per wave).
-template <int MT, int NT>
-__device__ __forceinline__ void store_acc(const ConvArgs &a, const f32x4 (&acc)[MT][NT], int wave, int lq, int l15,
-                                          int nb, int n0, int oy0, int ox0, int lgT, int TRm, int TCm) {
-    // epilogue: D layout col(n) = lane&15, row(m) = (lane>>4)*4 + reg
-    // (measured and dropped: reading the epilogue's parameters from the kernel-argument segment only here, to
-    // free scalar registers during the K loop — the private copy costs more vector registers than it frees)
-    if (a.vec4 && !a.res) {
-        // common case (rows of 4 pixels stored as one float4, no residual): the pixel part of the output
-        // address is worked out once per pixel tile, the channel part once per cout tile
-        const long planeO = (long)a.Hout * a.Wout;
-        const long planeY = a.up2 ? planeO * 4 : planeO;
-        const long W2 = 2L * a.Wout;
-        long poff[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int p = (wave * MT + mt) * 16 + lq * 4;
-            const int il = p >> lgT, r = (p >> a.lgTC) & TRm, cc = p & TCm;
-            const int n = n0 + il, oy = oy0 + r, ox = ox0 + cc;
-            const bool ok = n < a.N && oy < a.Hout && ox < a.Wout;
-            const long pix = a.up2 ? (long)(2 * oy) * W2 + 2 * ox : (long)oy * a.Wout + ox;
-            poff[mt] = ok ? (long)n * a.Cout * planeY + pix : -1;
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = nb * (NT * 16) + nt * 16 + l15;
-            if (co >= a.Cout) continue;
-            float sc = 1.f, sh = 0.f;
-            if (a.scale) {
-                sc = a.scale[co];
-                sh = a.shift[co];
-            } else if (a.bias) {
-                sh = a.bias[co];
-            }
-            float *yc = a.y + co * planeY;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (poff[mt] < 0) continue;
-                const f32x4 c = acc[mt][nt];
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act(c[j] * sc + sh, a.act);
-                float *q = yc + poff[mt];
-                if (a.up2) {
-                    const float4 lo = make_float4(v[0], v[0], v[1], v[1]), hi = make_float4(v[2], v[2], v[3], v[3]);
-                    *reinterpret_cast<float4 *>(q) = lo;
-                    *reinterpret_cast<float4 *>(q + 4) = hi;
-                    *reinterpret_cast<float4 *>(q + W2) = lo;
-                    *reinterpret_cast<float4 *>(q + W2 + 4) = hi;
-                } else {
-                    *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int pb = (wave * MT + mt) * 16 + lq * 4;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = nb * (NT * 16) + nt * 16 + l15;
-            store_tile(a, acc[mt][nt], pb, co, n0, oy0, ox0, lgT, TRm, TCm);
-        }
-    }
-}
-
 }  // namespace

@@ -1,6 +1,7 @@
 // libsprk.so: error reporting, diagnostics and the event-based kernel timing used by
 // bench.py's roofline leg.
 #include "common.h"
+#include "conv16.h"
 
 #include <mutex>
 #include <vector>
@@ -64,6 +65,7 @@ int sprk_version(void) { return 100; }
 long sprk_launch_count(void) { return sprk::g_launches.load(); }
 long sprk_wino_launch_count(void) { return sprk::g_wino_launches.load(); }
 void sprk_set_naive(int on) { sprk::g_naive = on ? 1 : 0; }
+long sprk_conv16_launch_count(void) { return sprk::conv16_launches(); }
 
 void sprk_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(sprk::g_prof_mu);

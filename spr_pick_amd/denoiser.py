@@ -110,6 +110,13 @@ class Denoiser(nn.Module):
             self.add_model(Denoiser.SIGMA_ESTIMATOR, DualNetworkShallow(in_channels=in_channels, out_channels=1,
                                                                         blindspot=False, detect=False))
 
+    def set_conv_dtype(self, dtype):
+        """"f32" (default) | "bf16" | "f16": operand precision of the U-Nets' MFMA convolutions (BASELINE configs[4];
+        networks.set_conv_dtype).  Parameters, activations, gradients and the optimiser stay fp32."""
+        from .networks import set_conv_dtype
+        self.conv_dtype = dtype
+        return set_conv_dtype(self, dtype)
+
     def fill(self, stride=1):
         return self.models[Denoiser.MODEL].fill(stride=stride)
 

@@ -53,6 +53,7 @@ class Conv2d(nn.Module):
         self.kernel_size = (kernel_size, kernel_size)
         self.stride, self.padding, self.dilation = stride, padding, dilation
         self.act = act
+        self.mfma_dtype = 0      # _lib.DT_*: operand precision of this layer's MFMA kernels (set_conv_dtype)
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
@@ -72,7 +73,7 @@ class Conv2d(nn.Module):
         """skip: second input source (channel concat); up: x is half resolution, upsampled on load;
         up_out: write the output nearest-upsampled x2 (the nn.Upsample that follows in the reference)."""
         return ops.conv2d(x, self.weight, self.bias, x2=skip, up1=up, stride=self.stride, dil=self.dilation,
-                          pad=self._pad(), act=self.act, up_out=up_out)
+                          pad=self._pad(), act=self.act, up_out=up_out, dtype=self.mfma_dtype)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%d, padding=%d, dilation=%d, act=%d%s" % (
@@ -165,6 +166,23 @@ class _UNetBase(nn.Module):
                 self.output_conv.weight.zero_()
             else:
                 nn.init.kaiming_normal_(self.output_conv.weight.data, nonlinearity="linear")
+
+
+def set_conv_dtype(module, dtype):
+    """Operand precision ("f32" | "bf16" | "f16") of the convolutions of every U-Net under ``module`` — the layers
+    that carry 99.6 % of the FLOPs.  The detector (BatchNorm statistics over 64-patch batches,
+    0.4 % of the FLOPs) and each U-Net's final 1x1 output convolution (it produces mu and the variance factor the
+    likelihood is evaluated on) always run in fp32.  Returns the number of layers switched."""
+    from ._lib import DTYPES
+    code = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+    n = 0
+    for net in module.modules():
+        if isinstance(net, _UNetBase):
+            for name, m in net.named_modules():
+                if isinstance(m, Conv2d) and not name.startswith("output_conv"):
+                    m.mfma_dtype = code
+                    n += 1
+    return n
 
 
 class DualNetwork(_UNetBase):

@@ -62,7 +62,7 @@ def conv_out_size(n, k, stride, dil, pad_lo, pad_hi):
     return (n + pad_lo + pad_hi - dil * (k - 1) - 1) // stride + 1
 
 
-def make_geom(x, x2, w, up1, stride, dil, pad, out_hw=None):
+def make_geom(x, x2, w, up1, stride, dil, pad, out_hw=None, dtype=0):
     """pad = (top, bottom, left, right) zero padding of the (virtual) conv input."""
     N, C1 = x.shape[0], x.shape[1]
     Hin, Win = (x.shape[2] * 2, x.shape[3] * 2) if up1 else (x.shape[2], x.shape[3])
@@ -79,7 +79,7 @@ def make_geom(x, x2, w, up1, stride, dil, pad, out_hw=None):
         Hout, Wout = out_hw
     if Hout <= 0 or Wout <= 0:
         raise ValueError("conv2d: input %dx%d too small for kernel %dx%d dil %d" % (Hin, Win, KH, KW, dil))
-    return ConvGeom(N, C1, C2, Hin, Win, 1 if up1 else 0, Cout, Hout, Wout, KH, KW, stride, dil, pt, pl)
+    return ConvGeom(N, C1, C2, Hin, Win, 1 if up1 else 0, Cout, Hout, Wout, KH, KW, stride, dil, pt, pl, int(dtype))
 
 
 def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None, res=None, res_off=0, up_out=False):
@@ -101,11 +101,11 @@ def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None,
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x2, w, bias, up1, stride, dil, pad, act, up_out):
+    def forward(ctx, x, x2, w, bias, up1, stride, dil, pad, act, up_out, dtype):
         x = x.contiguous()
         x2 = None if x2 is None else x2.contiguous()
         w = w.contiguous()
-        g = make_geom(x, x2, w, up1, stride, dil, pad)
+        g = make_geom(x, x2, w, up1, stride, dil, pad, dtype=dtype)
         y = conv2d_forward(x, x2, w, g, bias=bias, act=act, up_out=up_out)
         ctx.geom = g
         ctx.act = act
@@ -152,7 +152,7 @@ class _Conv2dFn(torch.autograd.Function):
                 # the skip source needs no gradient (the raw image x0 of decode_block_1): only the
                 # first C1 input channels are back-propagated
                 gd = ConvGeom(g.N, g.C1, 0, g.Hin, g.Win, g.up1, g.Cout, g.Hout, g.Wout, g.KH, g.KW, g.stride, g.dil,
-                              g.pad_top, g.pad_left)
+                              g.pad_top, g.pad_left, g.dtype)
                 wd = w[:, :g.C1].contiguous()
             gin = torch.empty((gd.N, gd.C1 + gd.C2, gd.Hin, gd.Win), dtype=torch.float32, device=gy.device)
             nb = L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(gd))
@@ -166,15 +166,18 @@ class _Conv2dFn(torch.autograd.Function):
                 gx2 = torch.empty_like(x2) if gd.C2 else None
                 check(L.sprk_concat_up_bwd(_p(gin), _p(gx), _p(gx2), gd.N, gd.C1, gd.C2, gd.Hin, gd.Win, gd.up1,
                                            _stream(gin)), "sprk_concat_up_bwd")
-        return gx, gx2, gw, gb, None, None, None, None, None, None
+        return gx, gx2, gw, gb, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, x2=None, up1=False, stride=1, dil=1, pad=(0, 0, 0, 0), act=ACT_NONE, up_out=False):
+def conv2d(x, w, bias=None, x2=None, up1=False, stride=1, dil=1, pad=(0, 0, 0, 0), act=ACT_NONE, up_out=False,
+           dtype=0):
     """y = act(conv(cat(up2(x) if up1 else x, x2), w) + bias); pad = (top, bottom, left, right).
-    up_out: return nearest-x2-upsampled y (the upsampling is fused into the conv's stores)."""
+    up_out: return nearest-x2-upsampled y (the upsampling is fused into the conv's stores).
+    dtype: _lib.DT_F32 / DT_BF16 / DT_F16 — precision of the MFMA operands in forward, backward-data and
+    backward-weight (a request: layers without a 16-bit kernel run in fp32; tensors are fp32 either way)."""
     _need_gpu(x, x2, w, bias)
     return _Conv2dFn.apply(x, x2, w, bias, bool(up1), int(stride), int(dil), tuple(int(p) for p in pad), int(act),
-                           bool(up_out))
+                           bool(up_out), int(dtype))
 
 
 # ---- U-Net plumbing -----------------------------------------------------------------------------

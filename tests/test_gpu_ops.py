@@ -380,3 +380,102 @@ def test_cpu_tensors_are_refused():
     from spr_pick_amd import _lib, ops
     with pytest.raises(_lib.SprkError):
         ops.conv2d(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 3, 3))
+
+
+# ---- 16-bit-operand MFMA convolutions (BASELINE configs[4]) ------------------------------------------------------
+CONV16_CASES = [
+    # name, N, C1, C2, H, W, Cout, K, pad(t,b,l,r), act, bias, up_out
+    ("c16 enc1.0 shift 1->48 @64", 8, 1, 0, 64, 64, 48, 3, (2, 0, 1, 1), 1, True, False),
+    ("c16 enc1.2 shift 48->48 @64 (MT=4)", 32, 48, 0, 64, 64, 48, 3, (2, 0, 1, 1), 1, True, False),
+    ("c16 enc2 shift 48->48 @32", 16, 48, 0, 32, 32, 48, 3, (2, 0, 1, 1), 1, True, False),
+    ("c16 enc3 shift 48->48 @16", 64, 48, 0, 16, 16, 48, 3, (2, 0, 1, 1), 1, True, False),
+    ("c16 dec3.0 shift 96+48->96 @32", 16, 96, 48, 32, 32, 96, 3, (2, 0, 1, 1), 1, True, False),
+    ("c16 dec2.2 shift 96->96 @32 up_out", 8, 96, 0, 32, 32, 96, 3, (2, 0, 1, 1), 1, True, True),
+    ("c16 dec1.0 shift 96+1->96 @64 (MT=4)", 32, 96, 1, 64, 64, 96, 3, (2, 0, 1, 1), 1, True, False),
+    ("c16 sigma plain 96+1->96 @64", 4, 96, 1, 64, 64, 96, 3, (1, 1, 1, 1), 1, True, False),
+    ("c16 dec1.2 shift 96->96 @64", 8, 96, 0, 64, 64, 96, 3, (2, 0, 1, 1), 1, True, False),
+    ("c16 head 1x1 384->384 @64", 4, 384, 0, 64, 64, 384, 1, (0, 0, 0, 0), 1, True, False),
+    ("c16 head 1x1 384->96 @64", 4, 384, 0, 64, 64, 96, 1, (0, 0, 0, 0), 1, True, False),
+    ("c16 ragged 40->70 @24x48 pad(1,1,2,0)", 6, 40, 0, 24, 48, 70, 3, (1, 1, 2, 0), 2, False, False),
+    ("c16 filled-size 48->48 @96x128", 1, 48, 0, 96, 128, 48, 3, (2, 0, 1, 1), 1, True, False),
+]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("case", CONV16_CASES, ids=[c[0] for c in CONV16_CASES])
+def test_conv2d_16bit_operands(case, dt):
+    """Forward and backward-data on v_mfma_f32_16x16x32_{bf16,f16} (conv16.hip), two statements:
+      (exact model)  the kernel computes conv(round16(x), round16(w)) with exact products and fp32 sums: against an
+                     fp64 convolution of the operands rounded on the CPU (torch RNE casts) the budget is the fp32
+                     path's own, 2e-5 / 5e-5 of the tensor scale — any wrong lane map, k order or missed conversion
+                     fails this by orders of magnitude;
+      (error bound)  against the UNROUNDED fp64 convolution every output is within 2u * sum_k |a_k| |w_k| + fp32
+                     slack, u = 2^-8 (bf16) / 2^-11 (fp16): the bound DESIGN.md states for the 16-bit path.
+    The launch counter proves the 16-bit kernel ran for forward and backward-data; the weight gradient is checked too
+    (on whichever backward-weight kernel the library picks for the dtype)."""
+    from spr_pick_amd import _lib, ops
+    name, N, C1, C2, H, W, Cout, K, pad, act, has_b, up_out = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    x = torch.randn(N, C1, H, W, generator=g)
+    x2 = torch.randn(N, C2, H, W, generator=g) if C2 else None
+    w = torch.randn(Cout, C1 + C2, K, K, generator=g) / np.sqrt((C1 + C2) * K * K)
+    b = torch.randn(Cout, generator=g) * 0.1 if has_b else None
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    u = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11     # unit roundoff: 8 / 11 significant bits, round to nearest
+    r16 = lambda t: None if t is None else t.to(tdt).double()
+    d = dev()
+    L = _lib.lib()
+    dl = [t.to(d).requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
+    n0 = L.sprk_conv16_launch_count()
+    y = ops.conv2d(dl[0], dl[2], dl[3], x2=dl[1], pad=pad, act=act, up_out=up_out, dtype=_lib.DTYPES[dt + "!"])
+    assert L.sprk_conv16_launch_count() == n0 + 1, "forward did not take the 16-bit kernel"
+    yv = y.detach().cpu()
+    if up_out:
+        assert torch.equal(yv[:, :, 0::2, 0::2], yv[:, :, 1::2, 1::2]) and torch.equal(yv[:, :, 0::2, 1::2], yv[:, :, 1::2, 0::2])
+        yv = yv[:, :, 0::2, 0::2]
+    bd = None if b is None else b.double()
+    pre_r = ref_conv(r16(x), r16(x2), r16(w), bd, 0, 1, 1, pad, 0)
+    act_f = (lambda t: F.leaky_relu(t, 0.1)) if act == 1 else (F.relu if act == 2 else (lambda t: t))
+    close(yv, act_f(pre_r), name=name + " y (exact model)")
+    pre_t = ref_conv(x.double(), None if x2 is None else x2.double(), w.double(), bd, 0, 1, 1, pad, 0)
+    xin = x if x2 is None else torch.cat((x, x2), 1)
+    mag = ref_conv(xin.double().abs(), None, w.double().abs(), None, 0, 1, 1, pad, 0)
+    err = (yv.double() - act_f(pre_t)).abs()
+    bound = 2 * u * mag + 2e-5 * pre_t.abs().max()
+    assert bool((err <= bound).all()), "%s: rounding bound violated: worst ratio %.3f" % (name, float((err / bound).max()))
+
+    # backward: gpre = gy * act'(y) is an fp32 product (act_bwd kernel); backward-data = conv16(round16(gpre), round16(w))
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy.to(d))
+    torch.cuda.synchronize()
+    # backward-data is a convolution over the layer's OUTPUT channels (k) producing its input channels (n): the
+    # 16-bit kernel takes it when k is 8m or 8m+1 and there are >= 33 input channels
+    bwd16 = Cout % 8 <= 1 and C1 + C2 >= 33
+    assert L.sprk_conv16_launch_count() >= n0 + 1 + int(bwd16), "backward-data did not take the 16-bit kernel"
+    gyl = gy
+    if up_out:
+        gyl = gy[:, :, 0::2, 0::2] + gy[:, :, 0::2, 1::2] + gy[:, :, 1::2, 0::2] + gy[:, :, 1::2, 1::2]
+    if act:
+        slope = torch.tensor(0.1 if act == 1 else 0.0)
+        gpre = torch.where(yv > 0, gyl, gyl * slope)
+    else:
+        gpre = gyl
+    pt, pb, pl, pr = pad
+    # d/d(input) of a stride-1 correlation = full correlation of gpre with the flipped, channel-transposed taps
+    wr = r16(w)
+    gin = F.conv_transpose2d(r16(gpre), wr)[:, :, pt:pt + H, pl:pl + W]
+    if bwd16 and not up_out:
+        close(dl[0].grad, gin[:, :C1], rel=5e-5, name=name + " gx (exact model)")
+        if x2 is not None:
+            close(dl[1].grad, gin[:, C1:], rel=5e-5, name=name + " gx2 (exact model)")
+    elif bwd16:
+        # the 2x2 sum of the upsampled gradient is an fp32 sum whose order is the kernel's: a different order moves a
+        # few gpre values across a 16-bit rounding boundary, so this case is held to the rounding budget instead
+        close(dl[0].grad, gin[:, :C1], rel=8 * u, name=name + " gx (rounding budget)")
+    # weight / bias gradient against the unrounded fp64 statement, 16-bit budget relative to the gradient's scale
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
+    pre = ref_conv(leaves[0], leaves[1], leaves[2], leaves[3], 0, 1, 1, pad, 0)
+    pre.backward(gpre.double())
+    close(dl[2].grad, leaves[2].grad, rel=8 * u, name=name + " gw")
+    if b is not None:
+        close(dl[3].grad, leaves[3].grad, rel=5e-5, name=name + " gb")

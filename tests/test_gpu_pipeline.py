@@ -395,3 +395,91 @@ def test_filled_inference_4096_and_nms(oracle_state):
     keep = picks.filter_picks(s, c, (S, S))
     kc = np.asarray(keep[1])
     assert len(kc) and kc.min() > 30 and kc.max() < S - 30
+
+
+# network-level budgets of the 16-bit-operand path (see the test's docstring): relative RMS of outputs / losses,
+# minimum cosine and norm deviation of every parameter gradient against the exact model's
+#   out = 4 u sqrt(L): u = 2^-8 / 2^-11, L = 23 convolutions on the U-Net's longest path (independent roundings add
+#   in quadrature: 2 u sqrt(L) at the U-Net output, doubled for the detector / variance division behind it);
+#   measured on the golden step: bf16 5.2 % (DETECT) and <= 1.8 % elsewhere, fp16 0.61 % and <= 0.23 %.
+#   Gradients, against the exact model's (the network is chaotic in the roundings — a one-ulp fp32 difference that
+#   flips a 16-bit rounding grows about 3x per layer — so this is a statistical statement): measured minimum cosine
+#   0.846 (bf16) / 0.990 (fp16), norms within 39 % / a few %.
+BUDGET16 = {"bf16": {"out": 4 * 2.0 ** -8 * 23 ** 0.5, "cos": 0.75, "norm": 0.6},
+            "f16": {"out": 4 * 2.0 ** -11 * 23 ** 0.5, "cos": 0.97, "norm": 0.15}}
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_joint_train_step_16bit_operands(denoiser, oracle_state, dt):
+    """BASELINE configs[4]: the joint training step with the U-Nets' MFMA operands in bf16 / fp16 (tensors, master
+    weights, accumulation and every non-convolution kernel fp32).
+
+    Kernel-level exactness is pinned per operator (test_gpu_ops.py: every output equals conv(round16(x), round16(w))
+    with exact products and fp32 sums to 2e-5).  At network level two statements, both statistical (relative RMS;
+    budgets and measured values at BUDGET16 above):
+    (1) against the oracle evaluated with the same EXACT MODEL (oracle/networks.py MODEL16: operands of the eligible
+        U-Net convolutions rounded in forward and backward-data, fp32 backward-weight) — also checks that the library
+        takes the 16-bit kernels for exactly the layers the model rounds (46 launches);
+    (2) against the reference's fp32 golden step: the precision a user trades for the speed.
+    Forced 16-bit ("bf16!") so that every layer the kernels cover is exercised, not only those where they are faster."""
+    import copy
+    from oracle import networks as onet
+    from oracle import pipeline
+    from spr_pick_amd import DetectionDataset, _lib
+    from spr_pick_amd.params import PipelineOutput as P
+    g = golden("joint_train_w.npz")
+    denoiser.train(); denoiser.unfill()
+    n_layers = denoiser.set_conv_dtype(dt + "!")
+    assert n_layers == 19 + 17       # every conv of the two U-Nets except their final output convolutions
+    L = _lib.lib()
+    n0 = L.sprk_conv16_launch_count()
+    data = DetectionDataset.make_batch(torch.from_numpy(g["inp"]), torch.from_numpy(g["target"]))
+    try:
+        o = denoiser.run_pipeline(data, float(g["alpha"]), float(g["tau"]), train=True,
+                                  eps=torch.from_numpy(g["eps"]).cuda(), eps_flip=torch.from_numpy(g["eps_flip"]).cuda(),
+                                  flip_p=float(g["flip_p"]))
+        torch.mean(o[P.LOSS]).backward()
+    finally:
+        denoiser.set_conv_dtype("f32")
+    ran16 = L.sprk_conv16_launch_count() - n0
+    assert ran16 >= 40, "only %d convolution launches took the 16-bit kernels" % ran16
+
+    sd = {k: v.clone() for k, v in oracle_state.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    onet.MODEL16["dtype"] = torch.bfloat16 if dt == "bf16" else torch.float16
+    try:
+        res = pipeline.joint_pipeline(sd, torch.from_numpy(g["inp"]), torch.from_numpy(g["target"]), float(g["alpha"]),
+                                      float(g["tau"]), True, torch.from_numpy(g["eps"]), torch.from_numpy(g["eps_flip"]),
+                                      float(g["flip_p"]))
+        res["LOSS"].mean().backward()
+    finally:
+        onet.MODEL16["dtype"] = None
+    def rel_rms(got, want):
+        got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+        return float(np.sqrt(np.mean((got - want) ** 2)) / (np.sqrt(np.mean(want ** 2)) + 1e-30))
+    model_err, ref_err = {}, {}
+    for key in ("LOSS", "DENOISE_LOSS", "DETECT", "IMG_MU", "IMG_DENOISED", "NOISE_STD_DEV", "MODEL_STD_DEV"):
+        got = o[getattr(P, key)].detach().cpu().numpy()
+        model_err[key] = rel_rms(got, res[key].detach().numpy())
+        ref_err[key] = rel_rms(got, g[key])
+    cos_min, norm_dev = 1.0, 0.0
+    biggest = max(float(v.grad.double().norm()) for v in sd.values() if v.requires_grad and v.grad is not None)
+    for name, p in denoiser.models.named_parameters():
+        want = sd[name].grad
+        if p.grad is None:
+            assert want is None, name
+            continue
+        a, b = p.grad.detach().cpu().double().ravel(), want.double().ravel()
+        if float(b.norm()) < 1e-2 * biggest:     # (near-)zero gradients, e.g. BatchNorm before BatchNorm: pure noise
+            continue
+        cos_min = min(cos_min, float(a @ b / (a.norm() * b.norm() + 1e-30)))
+        norm_dev = max(norm_dev, abs(float(a.norm() / b.norm()) - 1.0))
+    print("%s: %d 16-bit launches; rel. RMS vs exact model %s; vs fp32 reference %s; gradients vs exact model: min cosine "
+          "%.5f, worst |norm ratio - 1| %.4f" % (dt, ran16, {k: "%.1e" % v for k, v in model_err.items()},
+                                                  {k: "%.1e" % v for k, v in ref_err.items()}, cos_min, norm_dev))
+    budget = BUDGET16[dt]
+    assert all(v <= budget["out"] for v in model_err.values()), model_err
+    assert all(v <= budget["out"] for v in ref_err.values()), ref_err
+    assert cos_min >= budget["cos"] and norm_dev <= budget["norm"], (cos_min, norm_dev)
