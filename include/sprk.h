@@ -91,6 +91,8 @@ long sprk_wino_launch_count(void);
 /* number of convolution launches (forward, backward-data or backward-weight) that ran on the 16-bit-operand
  * kernels (diagnostics / tests) */
 long sprk_conv16_launch_count(void);
+/* ... of those, the backward-weight launches */
+long sprk_wgrad16_launch_count(void);
 /* debug switch: 1 = route convolutions through the direct (non-MFMA) kernels */
 void sprk_set_naive(int on);
 

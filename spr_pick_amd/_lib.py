@@ -36,6 +36,7 @@ _SIGS = {
     "sprk_launch_count": (ctypes.c_long, []),
     "sprk_wino_launch_count": (ctypes.c_long, []),
     "sprk_conv16_launch_count": (ctypes.c_long, []),
+    "sprk_wgrad16_launch_count": (ctypes.c_long, []),
     "sprk_set_naive": (None, [c_i]),
     "sprk_conv2d_fwd_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_fwd": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue), c_vp, c_sz, c_vp]),

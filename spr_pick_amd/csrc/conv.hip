@@ -18,6 +18,7 @@
 // cross-check (sprk_set_naive).
 #include "common.h"
 #include "conv16.h"
+#include "wgrad16.h"
 #include "wino.h"
 
 #include <cstdlib>
@@ -28,6 +29,7 @@
 namespace {
 
 constexpr int kClass16 = 5;   // profiling class of the 16-bit-operand forward / backward-data kernel (conv16.hip)
+constexpr int kClass16W = 6;  // ... of the 16-bit-operand backward-weight kernel (wgrad16.hip)
 
 // ------------------------------------------------------------------------------------------
 // weight transform:  W[Cout][Cin][KHW]  ->  Wt[nblk][rows][ldw]   (rows = k in chunked order)
@@ -1359,6 +1361,17 @@ sprk::Conv16Call call16_bwd(const sprk_conv_geom *g) {
     return c;
 }
 
+sprk::Wgrad16Call call16_wgrad(const sprk_conv_geom *g) {
+    sprk::Wgrad16Call c{};
+    c.dtype = g->dtype;
+    c.N = g->N; c.C1 = g->C1; c.C2 = g->C2; c.H = g->Hin; c.W = g->Win; c.Cout = g->Cout; c.Hout = g->Hout;
+    c.Wout = g->Wout; c.KH = g->KH; c.KW = g->KW; c.stride = g->stride; c.dil = g->dil; c.padT = g->pad_top;
+    c.padL = g->pad_left; c.up1 = g->up1;
+    c.kclass = kClass16W;
+    c.flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * g->KH * g->KW;
+    return c;
+}
+
 size_t wino_ws_fwd(const sprk_conv_geom *g) {
     return sprk::wino_eligible(wino_geom_fwd(g, nullptr)) ? sprk::wino_ws_bytes(g->C1, g->C2, g->Cout) : 0;
 }
@@ -1520,9 +1533,10 @@ size_t sprk_conv2d_bwd_weight_ws_bytes(const sprk_conv_geom *g) {
     if (!g) return 0;
     const size_t wino = sprk::wino_wgrad_eligible(wino_geom_fwd(g, nullptr))
                             ? sprk::wino_wgrad_ws_bytes(g->C1, g->C2, g->Cout) : 0;
+    const size_t w16 = (g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 ? sprk::wgrad16_ws_bytes(call16_wgrad(g)) : 0;
     WgPlan p;
-    if (!plan_wgrad(g, &p)) return wino;
-    return std::max(p.wsBytes, wino);
+    if (!plan_wgrad(g, &p)) return std::max(wino, w16);
+    return std::max(std::max(p.wsBytes, wino), w16);
 }
 
 int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, float *gw, const sprk_conv_geom *g,
@@ -1532,6 +1546,10 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     SPRK_REQUIRE(g->C2 == 0 || x2, "conv2d_bwd_weight: C2 > 0 but x2 is null");
     hipStream_t s = (hipStream_t)stream;
     const int Cin = g->C1 + g->C2;
+    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !sprk::g_naive) {
+        const sprk::Wgrad16Call c16 = call16_wgrad(g);
+        if (sprk::wgrad16_eligible(c16)) return sprk::wgrad16_run(c16, x, x2, gy, gw, ws, ws_bytes, s);
+    }
     if (!sprk::g_naive && sprk::wino_wgrad_eligible(wino_geom_fwd(g, nullptr))) {
         const size_t need = sprk::wino_wgrad_ws_bytes(g->C1, g->C2, g->Cout);
         if (ws_bytes < need || !ws) {

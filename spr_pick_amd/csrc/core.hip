@@ -2,6 +2,7 @@
 // bench.py's roofline leg.
 #include "common.h"
 #include "conv16.h"
+#include "wgrad16.h"
 
 #include <mutex>
 #include <vector>
@@ -65,7 +66,8 @@ int sprk_version(void) { return 100; }
 long sprk_launch_count(void) { return sprk::g_launches.load(); }
 long sprk_wino_launch_count(void) { return sprk::g_wino_launches.load(); }
 void sprk_set_naive(int on) { sprk::g_naive = on ? 1 : 0; }
-long sprk_conv16_launch_count(void) { return sprk::conv16_launches(); }
+long sprk_conv16_launch_count(void) { return sprk::conv16_launches() + sprk::wgrad16_launches(); }
+long sprk_wgrad16_launch_count(void) { return sprk::wgrad16_launches(); }
 
 void sprk_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(sprk::g_prof_mu);

@@ -1,0 +1,365 @@
+// 16-bit-operand backward-weight of the 3x3 stride-1 layers (gfx950 / MI355X):
+//   dW[cout][cin][ky][kx] = sum over images and pixels of  gy[n][cout][r][c] * x[n][cin][r + ky - padT][c + kx - padL]
+// on v_mfma_f32_16x16x32_{bf16,f16}.  As in conv16.hip the tensors are fp32 in HBM and only the two operands of each
+// product are rounded (round to nearest even); products exact, sums fp32.
+//
+// GEMM view: D[m = cout][n = cin] per tap, the reduced dimension k is the PIXEL.  A lane's 8 consecutive k are 8
+// consecutive pixels of one row of one channel plane, for both operands:
+//   A (lane: cout l&15, pixels 8(l>>4)..+7)  = one ds_read_b128 of the gy tile  [cout][128 pixels]            (16 bit)
+//   B (lane: cin  l&15, pixels 8(l>>4)..+7)  = one ds_read_b128 of the x tile   [cin][rows + 2][cols + 16]    (16 bit)
+//     at (row + ky, col + kx): the kx shift makes this read 2 or 4 bytes off 16-byte alignment, which gfx950's LDS
+//     serves (unaligned DS access); the tile is stored once, not once per shift.
+// Workgroup = 512 threads (8 waves, one per CU), persistent over REGIONS of 128 output pixels (2 x 64, 4 x 32 or
+// 8 x 16) of all images: it owns all (<= 96) output channels x a block of 48 input channels x 9 taps, i.e. 6 x 27
+// accumulator tiles, dealt to the waves as 6 cout tiles x {every 8th (cin tile, tap) pair}: 96 accumulator registers,
+// per k-step 6 + 4 LDS reads for 24 MFMAs.  The next region is fetched HBM -> registers (32-byte runs per lane, zeros
+// outside the image through the buffer range check) under the current region's MFMAs, converted once and written
+// to the other LDS stage; one barrier per region.  Each workgroup leaves one partial dW; wgrad16_reduce_kernel adds
+// them in a fixed order (deterministic).  gy is read once per 48-channel input block, x once.
+#include "wgrad16.h"
+
+#include "conv_dev.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct OpW;
+template <>
+struct OpW<__bf16> {
+    using v8 = bf16x8;
+    static __device__ __forceinline__ f32x4 mma(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <>
+struct OpW<_Float16> {
+    using v8 = f16x8;
+    static __device__ __forceinline__ f32x4 mma(v8 a, v8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+constexpr int kWgThreads = 512;
+constexpr int kCB = 48;          // input channels per block (3 tiles of 16)
+constexpr int kRegionPx = 128;   // output pixels per region = 4 k-steps of 32
+constexpr int kGyStride = 272;   // bytes per cout row of the gy tile: 128 pixels x 2 B + 16 (bank spread)
+
+struct Wg16Args {
+    const float *x, *x2, *gy;
+    float *partial;          // [parts][Cout][CinTot][9]
+    int N, C1, C2, H, W, Cout, padT, padL;
+    int lgRW, lgRH;          // region = 2^lgRH rows x 2^lgRW columns (128 pixels)
+    int regX, regY, nRegions;
+    int pitch;               // x tile columns (RW + 16), tile column 8 = the region's first output column
+    int xcs;                 // bytes per input channel of the x tile ((RH + 2) * pitch * 2, padded for bank spread)
+    int cinBase;             // first input channel of this launch's blocks is cinBase + blockIdx.y * 48
+    int diag;
+};
+
+template <typename T, int MC>   // MC: output-channel tiles (6: 81..96 channels, 3: 33..48)
+__global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
+    using V8 = typename OpW<T>::v8;
+    typedef const __attribute__((address_space(3))) V8 *lds_v8p;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int RW = 1 << a.lgRW, RH = 1 << a.lgRH;
+    const int CinTot = a.C1 + a.C2, HW = a.H * a.W;
+    const int cb0 = a.cinBase + blockIdx.y * kCB;              // first input channel of this block
+    const int cbn = min(kCB, CinTot - cb0);                    // channels present
+    const int gyBytes = MC * 16 * kGyStride, xBytes = kCB * a.xcs, stageBytes = gyBytes + xBytes;
+    const int lds0 = lds_addr(smem);
+    const int xRows = RH + 2;
+
+    // ---- fetch plan: 16-byte items, consecutive lanes on consecutive 16 bytes (fully coalesced buffer_load_dwordx4) ----
+    // gy items: (cout, 4-pixel group) — MC*16 channels x 32 groups;  x items: (cin, tile row, 4-column group); a
+    // 4-column group lies wholly inside or outside the image (W % 4 == 0, region origins multiples of 16)
+    constexpr int GYN = MC * 16 * 32 / kWgThreads;             // 6 (MC = 6) or 3
+    constexpr int XN = 8;                                      // 48 * 4 * 20 = 3840 <= 4096 items
+    const int xG4 = a.pitch >> 2;                              // 4-column groups per tile row
+    const int xPerCh = xRows * xG4, xItems = kCB * xPerCh;
+    const float invPerCh = 1.0f / (float)xPerCh, invG4 = 1.0f / (float)xG4;
+    typedef unsigned u32x4 __attribute__((__vector_size__(16)));
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    u32x4 fg[GYN], fx[XN];
+
+    auto region_origin = [&](int reg, int &n, int &r0, int &c0) {
+        const int rx = reg % a.regX;
+        const int t = reg / a.regX;
+        const int ry = t % a.regY;
+        n = t / a.regY;
+        r0 = ry << a.lgRH;
+        c0 = rx << a.lgRW;
+    };
+    auto fetch = [&](int reg) {
+        int n, r0, c0;
+        region_origin(reg, n, r0, c0);
+        const rsrc_t rg = make_rsrc(a.gy + (long)n * a.Cout * HW);
+        const int org = (r0 * a.W + c0) * 4;
+#pragma unroll
+        for (int i = 0; i < GYN; ++i) {
+            const int it = tid + i * kWgThreads;
+            const int co = it >> 5, p = (it & 31) * 4;
+            const int rr = p >> a.lgRW, cc = p & (RW - 1);
+            int off = org + ((co * a.H + rr) * a.W + cc) * 4;
+            if (co >= a.Cout || (a.diag & 1)) off = (int)0x80000000;     // beyond the range: zeros
+            fg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
+        }
+        const rsrc_t r1 = make_rsrc(a.x + (long)n * a.C1 * HW);
+        const rsrc_t r2 = make_rsrc(a.C2 ? a.x2 + (long)n * a.C2 * HW : a.x);
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int it = tid + i * kWgThreads;
+            const int cl = fast_div(it, invPerCh), rem = it - cl * xPerCh;
+            const int tr = fast_div(rem, invG4), g4 = rem - tr * xG4;
+            const int ch = cb0 + cl;
+            const int iy = r0 - a.padT + tr, ix = c0 - 8 + g4 * 4;
+            const bool ok = it < xItems && cl < cbn && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W &&
+                            !(a.diag & 1);
+            const bool s1 = ch < a.C1;
+            const int cc = s1 ? ch : ch - a.C1;
+            const int off = ok ? ((cc * a.H + iy) * a.W + ix) * 4 : (int)0x80000000;
+            // both sources are addressed; the one that does not hold the channel gets the out-of-range offset (zeros)
+            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(r1, s1 ? off : (int)0x80000000, 0, 0);
+            if (a.C2) {
+                const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(r2, s1 ? (int)0x80000000 : off, 0, 0);
+                fx[i] = v1 | v2;
+            } else {
+                fx[i] = v1;
+            }
+        }
+    };
+    auto cvt4 = [&](const u32x4 &v) {   // 4 fp32 -> 4 x 16 bit (8 bytes)
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        t4 r;
+        // (element first into a scalar: __builtin_bit_cast applied to a vector element expression reads element 0)
+        const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+        r[0] = (T)__uint_as_float(e0);
+        r[1] = (T)__uint_as_float(e1);
+        r[2] = (T)__uint_as_float(e2);
+        r[3] = (T)__uint_as_float(e3);
+        return __builtin_bit_cast(u16x4, r);
+    };
+    typedef __attribute__((address_space(3))) u16x4 *lds_u16x4w;
+    auto convert_store = [&](int b) {
+        const int sg = lds0 + b * stageBytes, sx = sg + gyBytes;
+#pragma unroll
+        for (int i = 0; i < GYN; ++i) {
+            const int it = tid + i * kWgThreads;
+            *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(sg + (it >> 5) * kGyStride + (it & 31) * 8) = cvt4(fg[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int it = tid + i * kWgThreads;
+            const int cl = fast_div(it, invPerCh), rem = it - cl * xPerCh;
+            const int tr = fast_div(rem, invG4), g4 = rem - tr * xG4;
+            if (it < xItems)
+                *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(sx + cl * a.xcs + (tr * a.pitch + g4 * 4) * 2) = cvt4(fx[i]);
+        }
+    };
+
+    // ---- this wave's accumulator tiles: all MC cout tiles x pairs {wave, wave + 8, wave + 16, wave + 24} of the 27
+    // (cin tile, tap) pairs of the block; pair q -> cin tile q / 9, tap q % 9
+    constexpr int NP = 4;
+    f32x4 acc[MC][NP];
+#pragma unroll
+    for (int m = 0; m < MC; ++m)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int boff[NP];   // byte offset of this lane's B operand inside the x tile for k-step 0, pair q (without the k-step part)
+    bool bok[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pr = wave + 8 * q;
+        bok[q] = pr < 27;
+        const int it = min(pr, 26) / 9, tap = min(pr, 26) % 9;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        // output pixel p = 32 ks + 8 kq + j of the region: row p >> lgRW, column p & (RW - 1); tile column of image
+        // column c0 + cc + kx - padL is 8 + cc + kx - padL
+        boff[q] = (it * 16 + l15) * a.xcs + (ky * a.pitch + 8 + kx - a.padL) * 2;
+    }
+    const int aoff = l15 * kGyStride;   // + cout tile * 16 * kGyStride + (ks * 4 + kq) * 16
+
+    int reg = blockIdx.x;
+    if (reg < a.nRegions) {
+        fetch(reg);
+        convert_store(0);
+    }
+    int b = 0;
+    for (; reg < a.nRegions; reg += gridDim.x, b ^= 1) {
+        __syncthreads();                       // stage b written by everyone; stage b^1 free again
+        const int next = reg + gridDim.x;
+        if (next < a.nRegions) fetch(next);    // in flight under this region's MFMAs
+        if (!(a.diag & 4)) {
+            const int sg = lds0 + b * stageBytes, sx = sg + gyBytes;
+#pragma unroll
+            for (int ks = 0; ks < kRegionPx / 32; ++ks) {
+                const int p = ks * 32 + kq * 8;
+                const int rr = p >> a.lgRW, cc = p & (RW - 1);
+                const int xo = sx + (rr * a.pitch + cc) * 2;
+                V8 av[MC], bv[NP];
+#pragma unroll
+                for (int m = 0; m < MC; ++m)
+                    av[m] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(sg + aoff + m * 16 * kGyStride + (ks * 4 + kq) * 16);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) bv[q] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(xo + boff[q]);
+#pragma unroll
+                for (int m = 0; m < MC; ++m)
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) acc[m][q] = OpW<T>::mma(av[m], bv[q], acc[m][q]);
+            }
+        }
+        if (next < a.nRegions) convert_store(b ^ 1);
+    }
+
+    // ---- partial dW of this workgroup: D layout col(n = cin) = lane & 15, row(m = cout) = (lane >> 4) * 4 + reg -------
+    float *part = a.partial + (long)blockIdx.x * a.Cout * CinTot * 9;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pr = wave + 8 * q;
+        if (pr >= 27) continue;
+        const int it = pr / 9, tap = pr - it * 9;
+        const int ci = cb0 + it * 16 + l15;
+        if (it * 16 + l15 >= cbn) continue;
+#pragma unroll
+        for (int m = 0; m < MC; ++m)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = m * 16 + kq * 4 + j;
+                if (co < a.Cout) part[((long)co * CinTot + ci) * 9 + tap] = bok[q] ? acc[m][q][j] : 0.f;
+            }
+    }
+}
+
+// gw[i] = sum over parts of partial[p][i], parts added in index order by 4 lanes x independent chains (fixed order)
+__global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw,
+                                                             long n, int parts) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 3 < parts; p += 4) {
+        s0 += partial[(long)p * n + i];
+        s1 += partial[(long)(p + 1) * n + i];
+        s2 += partial[(long)(p + 2) * n + i];
+        s3 += partial[(long)(p + 3) * n + i];
+    }
+    for (; p < parts; ++p) s0 += partial[(long)p * n + i];
+    gw[i] = (s0 + s1) + (s2 + s3);
+}
+
+struct PlanW {
+    int MC, lgRW, lgRH, regX, regY, nRegions, pitch, xcs, parts, nBlocks;
+    size_t ldsBytes, wsBytes;
+};
+
+int spread_stride(int bytes) {   // smallest stride >= bytes, multiple of 16, whose dword stride mod 64 is 4 * odd
+    int s = (bytes + 15) & ~15;
+    while (((s >> 2) & 7) != 4) s += 16;
+    return s;
+}
+
+std::atomic<long> g_wgrad16_launches{0};
+
+}  // namespace
+
+namespace sprk {
+
+static bool plan_wg16(const Wgrad16Call &c, PlanW *p) {
+    const int dt = c.dtype & SPRK_DT_MASK;
+    if (dt != SPRK_DT_BF16 && dt != SPRK_DT_F16) return false;
+    static const int on = getenv("SPRK_WGRAD16") ? atoi(getenv("SPRK_WGRAD16")) : 1;   // debug: 0 = fp32 kernels
+    if (!on) return false;
+    if (c.KH != 3 || c.KW != 3 || c.stride != 1 || c.dil != 1 || c.up1) return false;
+    if (c.Hout != c.H || c.Wout != c.W) return false;
+    if (c.padL < 0 || c.padL > 4 || c.padT < 0 || c.padT > 4) return false;
+    if (c.Cout < 33 || c.Cout > 96) return false;
+    const int W = c.W, H = c.H;
+    int RW;
+    if (W % 64 == 0) RW = 64;
+    else if (W == 32 || W == 16) RW = W;
+    else return false;
+    const int RH = kRegionPx / RW;
+    if (H % RH) return false;
+    p->MC = c.Cout > 48 ? 6 : 3;
+    p->lgRW = ilog2(RW); p->lgRH = ilog2(RH);
+    p->regX = W / RW; p->regY = H / RH;
+    const long regions = (long)c.N * p->regX * p->regY;
+    if (regions < 512 || regions > (1L << 30)) return false;
+    if ((long)std::max(std::max(c.C1, c.C2), c.Cout) * H * W * 4 >= (1L << 31)) return false;   // 32-bit byte offsets per image
+    p->nRegions = (int)regions;
+    p->pitch = RW + 16;
+    p->xcs = spread_stride((RH + 2) * p->pitch * 2);
+    if (kCB * (RH + 2) * (p->pitch / 4) > 8 * kWgThreads) return false;
+    p->nBlocks = cdiv(c.C1 + c.C2, kCB);
+    p->parts = std::max(1, std::min(256 / p->nBlocks, (int)(regions / 8)));
+    p->ldsBytes = 2 * ((size_t)p->MC * 16 * kGyStride + (size_t)kCB * p->xcs);
+    p->wsBytes = (size_t)p->parts * c.Cout * (c.C1 + c.C2) * 9 * sizeof(float);
+    return true;
+}
+
+bool wgrad16_eligible(const Wgrad16Call &c) {
+    PlanW p;
+    return plan_wg16(c, &p);
+}
+
+size_t wgrad16_ws_bytes(const Wgrad16Call &c) {
+    PlanW p;
+    return plan_wg16(c, &p) ? p.wsBytes : 0;
+}
+
+long wgrad16_launches() { return g_wgrad16_launches.load(); }
+
+int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const float *gy, float *gw, void *ws,
+                size_t ws_bytes, hipStream_t s) {
+    PlanW p;
+    if (!plan_wg16(c, &p)) {
+        set_error("wgrad16: geometry not eligible");
+        return SPRK_EINVAL;
+    }
+    if (ws_bytes < p.wsBytes || !ws) {
+        set_error("wgrad16: workspace too small (%zu < %zu)", ws_bytes, p.wsBytes);
+        return SPRK_EWORKSPACE;
+    }
+    Wg16Args a{};
+    a.x = x; a.x2 = x2; a.gy = gy; a.partial = (float *)ws;
+    a.N = c.N; a.C1 = c.C1; a.C2 = c.C2; a.H = c.H; a.W = c.W; a.Cout = c.Cout; a.padT = c.padT; a.padL = c.padL;
+    a.lgRW = p.lgRW; a.lgRH = p.lgRH; a.regX = p.regX; a.regY = p.regY; a.nRegions = p.nRegions;
+    a.pitch = p.pitch; a.xcs = p.xcs; a.cinBase = 0;
+    static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
+    a.diag = diag;
+    const int dt = c.dtype & SPRK_DT_MASK;
+    dim3 grid(p.parts, p.nBlocks);
+    auto go = [&](auto kernel) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)p.ldsBytes) != hipSuccess) {
+            set_error("wgrad16: cannot reserve %zu bytes of LDS", p.ldsBytes);
+            return (int)SPRK_ELAUNCH;
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(kWgThreads), p.ldsBytes, s, a);
+        return (int)SPRK_OK;
+    };
+    prof_begin(c.kclass, c.flops, s);
+    int rc;
+    if (dt == SPRK_DT_BF16)
+        rc = p.MC == 6 ? go(wgrad16_kernel<__bf16, 6>) : go(wgrad16_kernel<__bf16, 3>);
+    else
+        rc = p.MC == 6 ? go(wgrad16_kernel<_Float16, 6>) : go(wgrad16_kernel<_Float16, 3>);
+    if (rc) return rc;
+    prof_end(c.kclass, s);
+    if (int rc2 = check_launch("wgrad16")) return rc2;
+    const long n = (long)c.Cout * (c.C1 + c.C2) * 9;
+    hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float *)ws, gw, n, p.parts);
+    g_wgrad16_launches.fetch_add(1, std::memory_order_relaxed);
+    return check_launch("wgrad16_reduce");
+}
+
+}  // namespace sprk

@@ -398,6 +398,10 @@ CONV16_CASES = [
     ("c16 head 1x1 384->96 @64", 4, 384, 0, 64, 64, 96, 1, (0, 0, 0, 0), 1, True, False),
     ("c16 ragged 40->70 @24x48 pad(1,1,2,0)", 6, 40, 0, 24, 48, 70, 3, (1, 1, 2, 0), 2, False, False),
     ("c16 filled-size 48->48 @96x128", 1, 48, 0, 96, 128, 48, 3, (2, 0, 1, 1), 1, True, False),
+    # large enough (>= 512 regions of 128 pixels) for the 16-bit backward-weight kernel as well
+    ("c16 wgrad dec2.0 shift 96+48->96 @32", 64, 96, 48, 32, 32, 96, 3, (2, 0, 1, 1), 1, True, False),
+    ("c16 wgrad enc3 plain 48->48 @16", 256, 48, 0, 16, 16, 48, 3, (1, 1, 1, 1), 1, True, False),
+    ("c16 wgrad 40+30->88 @64x128 pad(1,1,2,0)", 8, 40, 30, 64, 128, 88, 3, (1, 1, 2, 0), 0, True, False),
 ]
 
 
@@ -426,7 +430,7 @@ def test_conv2d_16bit_operands(case, dt):
     d = dev()
     L = _lib.lib()
     dl = [t.to(d).requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
-    n0 = L.sprk_conv16_launch_count()
+    n0, w0 = L.sprk_conv16_launch_count(), L.sprk_wgrad16_launch_count()
     y = ops.conv2d(dl[0], dl[2], dl[3], x2=dl[1], pad=pad, act=act, up_out=up_out, dtype=_lib.DTYPES[dt + "!"])
     assert L.sprk_conv16_launch_count() == n0 + 1, "forward did not take the 16-bit kernel"
     yv = y.detach().cpu()
@@ -472,10 +476,20 @@ def test_conv2d_16bit_operands(case, dt):
         # the 2x2 sum of the upsampled gradient is an fp32 sum whose order is the kernel's: a different order moves a
         # few gpre values across a 16-bit rounding boundary, so this case is held to the rounding budget instead
         close(dl[0].grad, gin[:, :C1], rel=8 * u, name=name + " gx (rounding budget)")
-    # weight / bias gradient against the unrounded fp64 statement, 16-bit budget relative to the gradient's scale
+    # weight gradient: on the 16-bit backward-weight kernel (wgrad16.hip) when the layer is large enough — then it is
+    # conv_weight(round16(x), round16(gpre)) with exact products and fp32 sums (exact model, 1e-4: sums of up to
+    # 5e5 fp32 terms over 256 partial results) — otherwise on the fp32 kernels: the unrounded fp64 statement
+    wg16 = (K == 3 and 33 <= Cout <= 96 and (W % 64 == 0 or W in (16, 32)) and H % (128 // min(W, 64)) == 0
+            and N * H * W >= 65536 and not up_out)
+    assert L.sprk_wgrad16_launch_count() == w0 + int(wg16), "backward-weight kernel choice"
     leaves = [t.double().requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
     pre = ref_conv(leaves[0], leaves[1], leaves[2], leaves[3], 0, 1, 1, pad, 0)
     pre.backward(gpre.double())
+    if wg16:
+        xin = x if x2 is None else torch.cat((x, x2), 1)
+        xp = F.pad(r16(xin), (pad[2], pad[3], pad[0], pad[1]))
+        gw_model = torch.nn.grad.conv2d_weight(xp, w.shape, r16(gpre))
+        close(dl[2].grad, gw_model, rel=1e-4, name=name + " gw (exact model)")
     close(dl[2].grad, leaves[2].grad, rel=8 * u, name=name + " gw")
     if b is not None:
         close(dl[3].grad, leaves[3].grad, rel=5e-5, name=name + " gb")
