@@ -55,115 +55,114 @@ struct Wg16Args {
     const float *x, *x2, *gy;
     float *partial;          // [parts][Cout][CinTot][9]
     int N, C1, C2, H, W, Cout, padT, padL;
-    int lgRW, lgRH;          // region = 2^lgRH rows x 2^lgRW columns (128 pixels)
-    int regX, regY, nRegions;
-    int pitch;               // x tile columns (RW + 16), tile column 8 = the region's first output column
-    int xcs;                 // bytes per input channel of the x tile ((RH + 2) * pitch * 2, padded for bank spread)
-    int cinBase;             // first input channel of this launch's blocks is cinBase + blockIdx.y * 48
+    int regX, regY;          // regions per row of regions / per column (region = RH rows x RW columns = 128 pixels)
+    int seg, segLen;         // a strip (image, column block) is cut into `seg` vertical segments of segLen regions
+    int nUnits;              // N * regX * seg
+    int xcs;                 // bytes per input channel of the rolling x buffer (SLOTS rows x pitch x 2, bank spread)
     int diag;
 };
 
-template <typename T, int MC>   // MC: output-channel tiles (6: 81..96 channels, 3: 33..48)
+// LGRW: log2 of the region width (6: 2 rows x 64 columns, 5: 4 rows x 32 columns).
+// The x tile is a ROLLING window of SLOTS = 2 RH + 2 tile rows per channel: consecutive regions of a strip share RH + 2
+// - RH = 2 halo rows... precisely: region j reads tile rows j RH .. j RH + RH + 1 and only the RH rows below are new, so
+// x is fetched once (the first version re-fetched the halo rows of every region: 2x the bytes at 2-row regions).
+template <typename T, int MC, int LGRW>   // MC: output-channel tiles (6: 49..96 channels, 3: 33..48)
 __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     using V8 = typename OpW<T>::v8;
     typedef const __attribute__((address_space(3))) V8 *lds_v8p;
+    constexpr int RW = 1 << LGRW, RH = kRegionPx / RW, SLOTS = 2 * RH + 2;
+    constexpr int PITCH = RW + 16, XG4 = PITCH / 4;            // tile columns; column 8 = the region's first output column
+    constexpr int GYN = MC * 16 * 32 / kWgThreads;             // gy items (cout, 4-pixel group) per thread: 6 or 3
+    constexpr int XROWIT = kCB * XG4;                          // x items (cin, 4-column group) per tile row
+    constexpr int XN = (RH * XROWIT + kWgThreads - 1) / kWgThreads;   // per thread for a region's RH new rows: 4 or 5
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
-    const int RW = 1 << a.lgRW, RH = 1 << a.lgRH;
     const int CinTot = a.C1 + a.C2, HW = a.H * a.W;
-    const int cb0 = a.cinBase + blockIdx.y * kCB;              // first input channel of this block
+    const int cb0 = blockIdx.y * kCB;                          // first input channel of this block
     const int cbn = min(kCB, CinTot - cb0);                    // channels present
-    const int gyBytes = MC * 16 * kGyStride, xBytes = kCB * a.xcs, stageBytes = gyBytes + xBytes;
-    const int lds0 = lds_addr(smem);
-    const int xRows = RH + 2;
+    constexpr int gyBytes = MC * 16 * kGyStride;
+    const int ldsGy = lds_addr(smem), ldsX = ldsGy + 2 * gyBytes;
 
-    // ---- fetch plan: 16-byte items, consecutive lanes on consecutive 16 bytes (fully coalesced buffer_load_dwordx4) ----
-    // gy items: (cout, 4-pixel group) — MC*16 channels x 32 groups;  x items: (cin, tile row, 4-column group); a
-    // 4-column group lies wholly inside or outside the image (W % 4 == 0, region origins multiples of 16)
-    constexpr int GYN = MC * 16 * 32 / kWgThreads;             // 6 (MC = 6) or 3
-    constexpr int XN = 8;                                      // 48 * 4 * 20 = 3840 <= 4096 items
-    const int xG4 = a.pitch >> 2;                              // 4-column groups per tile row
-    const int xPerCh = xRows * xG4, xItems = kCB * xPerCh;
-    const float invPerCh = 1.0f / (float)xPerCh, invG4 = 1.0f / (float)xG4;
     typedef unsigned u32x4 __attribute__((__vector_size__(16)));
     typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-    u32x4 fg[GYN], fx[XN];
-
-    auto region_origin = [&](int reg, int &n, int &r0, int &c0) {
-        const int rx = reg % a.regX;
-        const int t = reg / a.regX;
-        const int ry = t % a.regY;
-        n = t / a.regY;
-        r0 = ry << a.lgRH;
-        c0 = rx << a.lgRW;
-    };
-    auto fetch = [&](int reg) {
-        int n, r0, c0;
-        region_origin(reg, n, r0, c0);
-        const rsrc_t rg = make_rsrc(a.gy + (long)n * a.Cout * HW);
-        const int org = (r0 * a.W + c0) * 4;
-#pragma unroll
-        for (int i = 0; i < GYN; ++i) {
-            const int it = tid + i * kWgThreads;
-            const int co = it >> 5, p = (it & 31) * 4;
-            const int rr = p >> a.lgRW, cc = p & (RW - 1);
-            int off = org + ((co * a.H + rr) * a.W + cc) * 4;
-            if (co >= a.Cout || (a.diag & 1)) off = (int)0x80000000;     // beyond the range: zeros
-            fg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
-        }
-        const rsrc_t r1 = make_rsrc(a.x + (long)n * a.C1 * HW);
-        const rsrc_t r2 = make_rsrc(a.C2 ? a.x2 + (long)n * a.C2 * HW : a.x);
-#pragma unroll
-        for (int i = 0; i < XN; ++i) {
-            const int it = tid + i * kWgThreads;
-            const int cl = fast_div(it, invPerCh), rem = it - cl * xPerCh;
-            const int tr = fast_div(rem, invG4), g4 = rem - tr * xG4;
-            const int ch = cb0 + cl;
-            const int iy = r0 - a.padT + tr, ix = c0 - 8 + g4 * 4;
-            const bool ok = it < xItems && cl < cbn && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W &&
-                            !(a.diag & 1);
-            const bool s1 = ch < a.C1;
-            const int cc = s1 ? ch : ch - a.C1;
-            const int off = ok ? ((cc * a.H + iy) * a.W + ix) * 4 : (int)0x80000000;
-            // both sources are addressed; the one that does not hold the channel gets the out-of-range offset (zeros)
-            const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(r1, s1 ? off : (int)0x80000000, 0, 0);
-            if (a.C2) {
-                const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(r2, s1 ? (int)0x80000000 : off, 0, 0);
-                fx[i] = v1 | v2;
-            } else {
-                fx[i] = v1;
-            }
-        }
-    };
+    typedef __attribute__((address_space(3))) u16x4 *lds_u16x4w;
     auto cvt4 = [&](const u32x4 &v) {   // 4 fp32 -> 4 x 16 bit (8 bytes)
         typedef T t4 __attribute__((ext_vector_type(4)));
-        t4 r;
         // (element first into a scalar: __builtin_bit_cast applied to a vector element expression reads element 0)
         const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+        t4 r;
         r[0] = (T)__uint_as_float(e0);
         r[1] = (T)__uint_as_float(e1);
         r[2] = (T)__uint_as_float(e2);
         r[3] = (T)__uint_as_float(e3);
         return __builtin_bit_cast(u16x4, r);
     };
-    typedef __attribute__((address_space(3))) u16x4 *lds_u16x4w;
-    auto convert_store = [&](int b) {
-        const int sg = lds0 + b * stageBytes, sx = sg + gyBytes;
+
+    // ---- per-thread item geometry (16-byte items: consecutive lanes on consecutive 16 bytes) -------------------------
+    int gyc[GYN], gyl[GYN];            // gy: byte offset inside an image relative to the region origin | LDS offset
 #pragma unroll
-        for (int i = 0; i < GYN; ++i) {
-            const int it = tid + i * kWgThreads;
-            *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(sg + (it >> 5) * kGyStride + (it & 31) * 8) = cvt4(fg[i]);
-        }
+    for (int i = 0; i < GYN; ++i) {
+        const int it = tid + i * kWgThreads;
+        const int co = it >> 5, p = (it & 31) * 4;
+        const int rr = p >> LGRW, cc = p & (RW - 1);
+        gyc[i] = (co < a.Cout && !(a.diag & 1)) ? ((co * a.H + rr) * a.W + cc) * 4 : (int)0x80000000;
+        gyl[i] = co * kGyStride + (it & 31) * 8;
+    }
+    // x items: byte offset inside the item's source relative to (tile row 0, column block), or the out-of-range marker |
+    // packed: LDS offset (bits 0-19), tile row within the fetch (bits 20-23, 15 = no item), source 2 flag (bit 24)
+    int xc[XN], xp[XN];
+    auto x_items = [&](int c0) {            // (re)computed per strip: column validity depends on the column block
 #pragma unroll
         for (int i = 0; i < XN; ++i) {
             const int it = tid + i * kWgThreads;
-            const int cl = fast_div(it, invPerCh), rem = it - cl * xPerCh;
-            const int tr = fast_div(rem, invG4), g4 = rem - tr * xG4;
-            if (it < xItems)
-                *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(sx + cl * a.xcs + (tr * a.pitch + g4 * 4) * 2) = cvt4(fx[i]);
+            const int rloc = it / XROWIT, rem = it - rloc * XROWIT;
+            const int cl = rem / XG4, g4 = rem - cl * XG4;
+            const int ch = cb0 + cl, ix = c0 - 8 + g4 * 4;
+            const bool ok = rloc < RH && cl < cbn && (unsigned)ix < (unsigned)a.W && !(a.diag & 1);
+            const bool s1 = ch < a.C1;
+            const int cc = s1 ? ch : ch - a.C1;
+            xc[i] = ok ? (cc * a.H * a.W + ix) * 4 : (int)0x80000000;
+            xp[i] = (cl * a.xcs + g4 * 8) | ((rloc < RH ? rloc : 15) << 20) | (s1 ? 0 : 1 << 24);
         }
+    };
+    u32x4 fg[GYN], fx[XN];
+    // fetch `rows` tile rows starting at tile row t0 (image row y0 + t0) of the strip: rows outside the image are zeros
+    auto fetch_x = [&](const rsrc_t r1, const rsrc_t r2, int y0, int t0, int rows) {
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int rloc = (xp[i] >> 20) & 15;
+            const int iy = y0 + t0 + rloc;
+            const bool ok = rloc < rows && (unsigned)iy < (unsigned)a.H && xc[i] >= 0;
+            const int off = ok ? xc[i] + iy * a.W * 4 : (int)0x80000000;
+            if (a.C2) {
+                const bool s2 = (xp[i] >> 24) & 1;
+                const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(r1, s2 ? (int)0x80000000 : off, 0, 0);
+                const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(r2, s2 ? off : (int)0x80000000, 0, 0);
+                fx[i] = v1 | v2;
+            } else {
+                fx[i] = __builtin_amdgcn_raw_buffer_load_b128(r1, off, 0, 0);
+            }
+        }
+    };
+    auto store_x = [&](int t0, int rows) {   // tile row t -> slot t mod SLOTS
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int rloc = (xp[i] >> 20) & 15;
+            const int slot = (t0 + rloc) % SLOTS;
+            if (rloc < rows)
+                *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(ldsX + (xp[i] & 0xFFFFF) + slot * (PITCH * 2)) = cvt4(fx[i]);
+        }
+    };
+    auto fetch_gy = [&](const rsrc_t rg, int org) {
+#pragma unroll
+        for (int i = 0; i < GYN; ++i) fg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, gyc[i], org, 0);
+    };
+    auto store_gy = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < GYN; ++i)
+            *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(ldsGy + b * gyBytes + gyl[i]) = cvt4(fg[i]);
     };
 
     // ---- this wave's accumulator tiles: all MC cout tiles x pairs {wave, wave + 8, wave + 16, wave + 24} of the 27
@@ -174,50 +173,72 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     for (int m = 0; m < MC; ++m)
 #pragma unroll
         for (int q = 0; q < NP; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int boff[NP];   // byte offset of this lane's B operand inside the x tile for k-step 0, pair q (without the k-step part)
-    bool bok[NP];
+    int blane[NP], bky[NP];   // lane part of the B address (channel, tap column, pixel group) | tap row (wave-uniform)
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-        const int pr = wave + 8 * q;
-        bok[q] = pr < 27;
-        const int it = min(pr, 26) / 9, tap = min(pr, 26) % 9;
+        const int pr = min(wave + 8 * q, 26);
+        const int it = pr / 9, tap = pr - it * 9;
         const int ky = tap / 3, kx = tap - ky * 3;
-        // output pixel p = 32 ks + 8 kq + j of the region: row p >> lgRW, column p & (RW - 1); tile column of image
-        // column c0 + cc + kx - padL is 8 + cc + kx - padL
-        boff[q] = (it * 16 + l15) * a.xcs + (ky * a.pitch + 8 + kx - a.padL) * 2;
+        bky[q] = __builtin_amdgcn_readfirstlane(ky);
+        blane[q] = ldsX + (it * 16 + l15) * a.xcs + (8 + kx - a.padL + kq * 8) * 2;
     }
-    const int aoff = l15 * kGyStride;   // + cout tile * 16 * kGyStride + (ks * 4 + kq) * 16
+    const int alane = ldsGy + l15 * kGyStride + kq * 16;
 
-    int reg = blockIdx.x;
-    if (reg < a.nRegions) {
-        fetch(reg);
-        convert_store(0);
-    }
-    int b = 0;
-    for (; reg < a.nRegions; reg += gridDim.x, b ^= 1) {
-        __syncthreads();                       // stage b written by everyone; stage b^1 free again
-        const int next = reg + gridDim.x;
-        if (next < a.nRegions) fetch(next);    // in flight under this region's MFMAs
-        if (!(a.diag & 4)) {
-            const int sg = lds0 + b * stageBytes, sx = sg + gyBytes;
+    for (int u = blockIdx.x; u < a.nUnits; u += gridDim.x) {
+        const int sgi = u % a.seg;
+        const int t = u / a.seg;
+        const int cx = t % a.regX, n = t / a.regX;
+        const int c0 = cx << LGRW;
+        const int ry0 = sgi * a.segLen, nreg = min(a.segLen, a.regY - ry0);
+        const int y0 = ry0 * RH - a.padT;                  // image row of tile row 0 of this unit
+        x_items(c0);
+        const rsrc_t rg = make_rsrc(a.gy + (long)n * a.Cout * HW);
+        const rsrc_t r1 = make_rsrc(a.x + (long)n * a.C1 * HW);
+        const rsrc_t r2 = make_rsrc(a.C2 ? a.x2 + (long)n * a.C2 * HW : a.x);
+        __syncthreads();                                   // the previous unit's last region has been consumed
+        // prologue: the two halo rows on top, then region 0's RH rows and its gy tile
+        fetch_x(r1, r2, y0, 0, 2);
+        store_x(0, 2);
+        fetch_x(r1, r2, y0, 2, RH);
+        fetch_gy(rg, ((ry0 * RH) * a.W + c0) * 4);
+        store_x(2, RH);
+        store_gy(0);
+        for (int j = 0; j < nreg; ++j) {
+            __syncthreads();                               // region j's tiles are complete; the older ones are free
+            const bool more = j + 1 < nreg;
+            if (more) {                                    // next region: in flight under this region's MFMAs
+                fetch_x(r1, r2, y0, 2 + (j + 1) * RH, RH);
+                fetch_gy(rg, (((ry0 + j + 1) * RH) * a.W + c0) * 4);
+            }
+            if (!(a.diag & 4)) {
+                const int ga = alane + (j & 1) * gyBytes;
+                const int jrow = (j * RH) % SLOTS;
 #pragma unroll
-            for (int ks = 0; ks < kRegionPx / 32; ++ks) {
-                const int p = ks * 32 + kq * 8;
-                const int rr = p >> a.lgRW, cc = p & (RW - 1);
-                const int xo = sx + (rr * a.pitch + cc) * 2;
-                V8 av[MC], bv[NP];
+                for (int ks = 0; ks < kRegionPx / 32; ++ks) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int rr = (ks * 32) >> LGRW;                     // region row of this k-step (compile time)
+                    const int cc2 = ((ks * 32) & (RW - 1)) * 2;           // byte offset of its first column
+                    V8 av[MC], bv[NP];
 #pragma unroll
-                for (int m = 0; m < MC; ++m)
-                    av[m] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(sg + aoff + m * 16 * kGyStride + (ks * 4 + kq) * 16);
+                    for (int m = 0; m < MC; ++m)
+                        av[m] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(ga + m * 16 * kGyStride + ks * 64);
 #pragma unroll
-                for (int q = 0; q < NP; ++q) bv[q] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(xo + boff[q]);
+                    for (int q = 0; q < NP; ++q) {
+                        const int slot = (jrow + rr + bky[q]) % SLOTS;    // scalar
+                        bv[q] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(blane[q] + slot * (PITCH * 2) + cc2);
+                    }
 #pragma unroll
-                for (int m = 0; m < MC; ++m)
+                    for (int m = 0; m < MC; ++m)
 #pragma unroll
-                    for (int q = 0; q < NP; ++q) acc[m][q] = OpW<T>::mma(av[m], bv[q], acc[m][q]);
+                        for (int q = 0; q < NP; ++q) acc[m][q] = OpW<T>::mma(av[m], bv[q], acc[m][q]);
+                }
+            }
+            if (more) {
+                store_x(2 + (j + 1) * RH, RH);
+                store_gy((j + 1) & 1);
             }
         }
-        if (next < a.nRegions) convert_store(b ^ 1);
     }
 
     // ---- partial dW of this workgroup: D layout col(n = cin) = lane & 15, row(m = cout) = (lane >> 4) * 4 + reg -------
@@ -234,7 +255,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int co = m * 16 + kq * 4 + j;
-                if (co < a.Cout) part[((long)co * CinTot + ci) * 9 + tap] = bok[q] ? acc[m][q][j] : 0.f;
+                if (co < a.Cout) part[((long)co * CinTot + ci) * 9 + tap] = acc[m][q][j];
             }
     }
 }
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float *__rest
 }
 
 struct PlanW {
-    int MC, lgRW, lgRH, regX, regY, nRegions, pitch, xcs, parts, nBlocks;
+    int MC, lgRW, regX, regY, seg, segLen, nUnits, xcs, parts, nBlocks;
     size_t ldsBytes, wsBytes;
 };
 
@@ -285,23 +306,27 @@ static bool plan_wg16(const Wgrad16Call &c, PlanW *p) {
     const int W = c.W, H = c.H;
     int RW;
     if (W % 64 == 0) RW = 64;
-    else if (W == 32 || W == 16) RW = W;
+    else if (W == 32) RW = 32;
     else return false;
     const int RH = kRegionPx / RW;
     if (H % RH) return false;
     p->MC = c.Cout > 48 ? 6 : 3;
-    p->lgRW = ilog2(RW); p->lgRH = ilog2(RH);
+    p->lgRW = ilog2(RW);
     p->regX = W / RW; p->regY = H / RH;
     const long regions = (long)c.N * p->regX * p->regY;
     if (regions < 512 || regions > (1L << 30)) return false;
     if ((long)std::max(std::max(c.C1, c.C2), c.Cout) * H * W * 4 >= (1L << 31)) return false;   // 32-bit byte offsets per image
-    p->nRegions = (int)regions;
-    p->pitch = RW + 16;
-    p->xcs = spread_stride((RH + 2) * p->pitch * 2);
-    if (kCB * (RH + 2) * (p->pitch / 4) > 8 * kWgThreads) return false;
     p->nBlocks = cdiv(c.C1 + c.C2, kCB);
-    p->parts = std::max(1, std::min(256 / p->nBlocks, (int)(regions / 8)));
-    p->ldsBytes = 2 * ((size_t)p->MC * 16 * kGyStride + (size_t)kCB * p->xcs);
+    const int wgs = std::max(1, 256 / p->nBlocks);         // workgroups per input-channel block: one per CU in all
+    // vertical segments per strip: enough units to give every workgroup >= 2, segments of >= 4 regions
+    int seg = 1;
+    while ((long)c.N * p->regX * seg < 2L * wgs && p->regY % (seg * 2) == 0 && p->regY / (seg * 2) >= 4) seg *= 2;
+    p->seg = seg; p->segLen = p->regY / seg;
+    p->nUnits = c.N * p->regX * seg;
+    p->parts = std::min(wgs, p->nUnits);
+    const int SLOTS = 2 * RH + 2, PITCH = RW + 16;
+    p->xcs = spread_stride(SLOTS * PITCH * 2);
+    p->ldsBytes = 2 * (size_t)p->MC * 16 * kGyStride + (size_t)kCB * p->xcs;
     p->wsBytes = (size_t)p->parts * c.Cout * (c.C1 + c.C2) * 9 * sizeof(float);
     return true;
 }
@@ -332,8 +357,7 @@ int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const flo
     Wg16Args a{};
     a.x = x; a.x2 = x2; a.gy = gy; a.partial = (float *)ws;
     a.N = c.N; a.C1 = c.C1; a.C2 = c.C2; a.H = c.H; a.W = c.W; a.Cout = c.Cout; a.padT = c.padT; a.padL = c.padL;
-    a.lgRW = p.lgRW; a.lgRH = p.lgRH; a.regX = p.regX; a.regY = p.regY; a.nRegions = p.nRegions;
-    a.pitch = p.pitch; a.xcs = p.xcs; a.cinBase = 0;
+    a.regX = p.regX; a.regY = p.regY; a.seg = p.seg; a.segLen = p.segLen; a.nUnits = p.nUnits; a.xcs = p.xcs;
     static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
     a.diag = diag;
     const int dt = c.dtype & SPRK_DT_MASK;
@@ -347,12 +371,13 @@ int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const flo
         hipLaunchKernelGGL(kernel, grid, dim3(kWgThreads), p.ldsBytes, s, a);
         return (int)SPRK_OK;
     };
+    auto pick = [&](auto tag) {
+        using T = decltype(tag);
+        if (p.lgRW == 6) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 6>) : go(wgrad16_kernel<T, 3, 6>);
+        return p.MC == 6 ? go(wgrad16_kernel<T, 6, 5>) : go(wgrad16_kernel<T, 3, 5>);
+    };
     prof_begin(c.kclass, c.flops, s);
-    int rc;
-    if (dt == SPRK_DT_BF16)
-        rc = p.MC == 6 ? go(wgrad16_kernel<__bf16, 6>) : go(wgrad16_kernel<__bf16, 3>);
-    else
-        rc = p.MC == 6 ? go(wgrad16_kernel<_Float16, 6>) : go(wgrad16_kernel<_Float16, 3>);
+    const int rc = dt == SPRK_DT_BF16 ? pick(__bf16{}) : pick(_Float16{});
     if (rc) return rc;
     prof_end(c.kclass, s);
     if (int rc2 = check_launch("wgrad16")) return rc2;

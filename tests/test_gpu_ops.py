@@ -400,7 +400,8 @@ CONV16_CASES = [
     ("c16 filled-size 48->48 @96x128", 1, 48, 0, 96, 128, 48, 3, (2, 0, 1, 1), 1, True, False),
     # large enough (>= 512 regions of 128 pixels) for the 16-bit backward-weight kernel as well
     ("c16 wgrad dec2.0 shift 96+48->96 @32", 64, 96, 48, 32, 32, 96, 3, (2, 0, 1, 1), 1, True, False),
-    ("c16 wgrad enc3 plain 48->48 @16", 256, 48, 0, 16, 16, 48, 3, (1, 1, 1, 1), 1, True, False),
+    ("c16 wgrad enc2 plain 48->48 @32", 64, 48, 0, 32, 32, 48, 3, (1, 1, 1, 1), 1, True, False),
+    ("c16 wgrad 2 segments 96->96 @128x64", 4, 96, 0, 128, 64, 96, 3, (2, 0, 1, 1), 1, True, False),
     ("c16 wgrad 40+30->88 @64x128 pad(1,1,2,0)", 8, 40, 30, 64, 128, 88, 3, (1, 1, 2, 0), 0, True, False),
 ]
 
@@ -479,7 +480,7 @@ def test_conv2d_16bit_operands(case, dt):
     # weight gradient: on the 16-bit backward-weight kernel (wgrad16.hip) when the layer is large enough — then it is
     # conv_weight(round16(x), round16(gpre)) with exact products and fp32 sums (exact model, 1e-4: sums of up to
     # 5e5 fp32 terms over 256 partial results) — otherwise on the fp32 kernels: the unrounded fp64 statement
-    wg16 = (K == 3 and 33 <= Cout <= 96 and (W % 64 == 0 or W in (16, 32)) and H % (128 // min(W, 64)) == 0
+    wg16 = (K == 3 and 33 <= Cout <= 96 and (W % 64 == 0 or W == 32) and H % (128 // min(W, 64)) == 0
             and N * H * W >= 65536 and not up_out)
     assert L.sprk_wgrad16_launch_count() == w0 + int(wg16), "backward-weight kernel choice"
     leaves = [t.double().requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
