@@ -285,7 +285,7 @@ def main():
     c0 = time.thread_time()
     for i in range(args.steps):
         o = step(args.warmup + i)
-    t_cpu = time.thread_time() - c0           # CPU time the launching thread spent (not waiting) on the steps
+    t_cpu = time.thread_time() - c0           # CPU time of the launching thread (includes spinning on a full queue)
     t_enq = time.perf_counter() - t0          # wall time until the last step was enqueued (the host may run at
                                               # most 8 steps ahead: the pinned upload ring of the labels)
     fence()
@@ -297,6 +297,14 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+
+    # host cost of enqueueing a step, measured on an idle queue (nothing to wait for): 6 steps from a synchronised GPU
+    fence()
+    te0 = time.perf_counter()
+    for i in range(6):
+        step(args.warmup + args.steps + i)
+    t_host = (time.perf_counter() - te0) / 6
+    fence()
 
     if use_graph:
         L.sprk_prof_enable(1 << DOM)
@@ -435,6 +443,8 @@ def main():
         "all_conv_mfma_tflops": all_fl / (all_ms * 1e-3) / 1e12 if all_ms > 0 else 0.0,
         "kernel_launches_per_step": (stepper.kernels_per_step if use_graph else launches / args.steps),
         "host_launch_calls_per_step": launches / args.steps,
+        "host_enqueue_ms_per_step": t_host * 1e3,
+        "host_enqueue_note": "wall time per step until the launching thread has enqueued it, from an idle queue (6 steps)",
         "host_cpu_ms_per_step": t_cpu / args.steps * 1e3,
         "host_enqueue_wall_ms_per_step": t_enq / args.steps * 1e3,
         "final_loss": last_loss, "kernel_source_hash": khash,

@@ -32,13 +32,15 @@ def disk_offsets(r):
             if di * di + dj * dj <= r * r]
 
 
-def nms_literal(x, r, threshold=-np.inf):
+def nms_literal(x, r, threshold=-np.inf, contam=None):
     x = np.ascontiguousarray(x, dtype=np.float32)
     H, W = x.shape
     A = x.ravel()
     order = np.argsort(A, kind="stable")[::-1]
     offs = disk_offsets(r)
-    suppressed = set()
+    # the reference walks and MUTATES the caller's set (utils/algorithms.py:77,98-101): indices already in it are
+    # neither emitted nor do they suppress anything
+    suppressed = contam if contam is not None else set()
     scores, coords = [], []
     for i in order:
         i = int(i)

@@ -12,14 +12,15 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py --cpu-seconds 12 > $OUT/bench.log 2>&1
 grep '^{"metric"' $OUT/bench.log > $OUT/bench.json
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --infer-size 0 --infer-large 0"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --infer-size 0 --infer-large 0 --also-dtype none --graph off"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
 grep '^{"metric"' $OUT/trace.log > $OUT/bench_under_rocprof.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w -- python3 $R/bench.py $ARGS > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d $OUT/mfma -o m -- python3 $R/bench.py $ARGS > $OUT/mfma.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/trace16 -o t -- python3 $R/bench.py $ARGS --dtype bf16 --also-dtype none > $OUT/trace16.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/infer -o i -- python3 $R/scratch/infer_prof.py 4096 > $OUT/infer.log 2>&1
 mkdir -p $OUT/summary
 python3 $R/profiles/summarize.py $OUT $TAG $OUT/summary
-rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/mfma $OUT/infer
+rm -rf $OUT/trace $OUT/trace16 $OUT/fetch $OUT/write $OUT/mfma $OUT/infer
 ls $OUT/summary

@@ -24,7 +24,27 @@ def db(sub):
     return sqlite3.connect(os.path.join(d, f))
 
 
+def demangle(name):
+    """_ZN12_GLOBAL__N_118conv16_tile_kernelIDF16bLi6EEEvNS_10Tile16ArgsE -> conv16_tile_kernel<bf16, 6> (rocprofv3 leaves the
+    kernels with a __bf16 / _Float16 template argument mangled)."""
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if not m:
+        return name
+    n = int(m.group(1))
+    base = name[m.end():m.end() + n]
+    rest = name[m.end() + n:]
+    args = []
+    if rest.startswith("I"):
+        for tok in re.findall(r"DF16b|DF16_|Li(\d+)E|Lb([01])E", rest.split("EEv")[0]):
+            pass
+        for mm in re.finditer(r"DF16b|DF16_|Li\d+E|Lb[01]E", rest.split("EEv")[0]):
+            t = mm.group(0)
+            args.append("bf16" if t == "DF16b" else "f16" if t == "DF16_" else t[2:-1] if t[1] == "i" else ("true" if t[2] == "1" else "false"))
+    return base + ("<" + ", ".join(args) + ">" if args else "")
+
+
 def short(name):
+    name = demangle(name)
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     return re.sub(r"\(.*$", "", name)
@@ -36,6 +56,9 @@ def family(name):
     if m:
         return "%s<%s, %s>" % m.groups()
     m = re.match(r"(wino_conv_kernel)<(\d+),", name)   # <NT, tile geometry> -> <NT>
+    if m:
+        return "%s<%s>" % m.groups()
+    m = re.match(r"(conv16_tile_kernel|conv16_mfma_kernel|wgrad16_kernel)<[^,]+, (\d+)", name)   # <dtype, NT/MT/MC, ...>
     if m:
         return "%s<%s>" % m.groups()
     m = re.match(r"(conv_wgrad_mfma_kernel)<", name)
@@ -80,6 +103,9 @@ def kernel_csv(sub, name, note):
             w.writerow([k, c, t, "%.1f" % (t / c), "%.3f" % (100.0 * t / total)])
 
 
+if os.path.isdir(os.path.join(src, "trace16")):
+    kernel_csv("trace16", tag + "_bench_bf16_kernel_stats.csv",
+               "bench.py --dtype bf16 (U-Net MFMA operands in bf16): kernel trace of 3 warm-up + 10 timed + event steps")
 if os.path.isdir(os.path.join(src, "infer")):
     kernel_csv("infer", tag + "_infer4096_kernel_stats.csv",
                "scratch/infer_prof.py 4096: three filled 4096x4096 inferences + NMS (first one includes warm-up)")

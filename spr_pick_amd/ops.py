@@ -1,15 +1,21 @@
-"""torch autograd operators over the libsprk.so C ABI (include/sprk.h).
+"""Differentiable operators over the libsprk.so C ABI (include/sprk.h).
 
-Every operator here launches hand-written HIP kernels on torch's current stream through
-ctypes; PyTorch only provides device memory, the stream and the autograd tape.  There is no
-alternative implementation: CPU tensors or a missing library raise.
+Two layers: torch_ops.py registers every C entry point as a PyTorch custom operator (``torch.ops.sprk.*``:
+schema, CUDA implementation = the ctypes call on torch's current stream, fake implementation for shape
+propagation); this module adds the autograd formulas (``autograd.Function`` classes whose forward AND backward are
+``torch.ops.sprk`` calls) and the functional API the networks use.  PyTorch provides device memory, the stream, the
+dispatcher and the autograd tape; there is no alternative implementation: CPU tensors or a missing library raise.
 """
 import ctypes
 
 import torch
 
 from . import _lib
+from . import torch_ops  # noqa: F401  (registers torch.ops.sprk.*)
 from ._lib import ACT_LEAKY, ACT_NONE, ACT_RELU, ConvEpilogue, ConvGeom, check  # noqa: F401
+from .torch_ops import geom_list
+
+_S = torch.ops.sprk
 
 
 def _stream(t):
@@ -85,18 +91,8 @@ def make_geom(x, x2, w, up1, stride, dil, pad, out_hw=None, dtype=0):
 def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None, res=None, res_off=0, up_out=False):
     """Raw forward launch (no autograd).  Returns y [N,Cout,Hout,Wout] ([N,Cout,2Hout,2Wout] with
     ``up_out``: nearest x2 upsampling fused into the store)."""
-    L = _lib.lib()
     _need_gpu(x, x2, w, bias, scale, shift, res)
-    m = 2 if up_out else 1
-    y = torch.empty((g.N, g.Cout, g.Hout * m, g.Wout * m), dtype=torch.float32, device=x.device)
-    ep = ConvEpilogue(_p(bias), _p(scale), _p(shift), _p(res),
-                      0 if res is None else res.shape[2], 0 if res is None else res.shape[3], res_off, act,
-                      1 if up_out else 0)
-    nb = L.sprk_conv2d_fwd_ws_bytes(ctypes.byref(g))
-    ws = _ws(nb, x)
-    check(L.sprk_conv2d_fwd(_p(x), _p(x2), _p(w), _p(y), ctypes.byref(g), ctypes.byref(ep), _p(ws), nb, _stream(x)),
-          "sprk_conv2d_fwd")
-    return y
+    return _S.conv2d_fwd(x, x2, w, bias, scale, shift, res, geom_list(g), int(res_off), int(act), 1 if up_out else 0)
 
 
 class _Conv2dFn(torch.autograd.Function):
@@ -116,7 +112,6 @@ class _Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        L = _lib.lib()
         x, x2, w, y, bias = ctx.saved_tensors
         g = ctx.geom
         gy = gy.contiguous()
@@ -126,24 +121,16 @@ class _Conv2dFn(torch.autograd.Function):
         # gradient w.r.t. the pre-activation output (+ bias gradient)
         up2 = 1 if ctx.up_out else 0
         if ctx.act != ACT_NONE or need_b or up2:
-            if ctx.act != ACT_NONE or up2:
-                gpre = torch.empty((g.N, g.Cout, g.Hout, g.Wout), dtype=torch.float32, device=gy.device)
-            else:
-                gpre = gy
+            want_gpre = ctx.act != ACT_NONE or bool(up2)
             if need_b:
                 gb = _grad_like(bias)
-            nb = L.sprk_act_bwd_ws_bytes(g.N, g.Cout, g.Hout * g.Wout)
-            ws = _ws(nb, gy)
-            check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre) if gpre is not gy else None, _p(gb), ctx.act,
-                                 g.N, g.Cout, g.Hout, g.Wout, up2, _p(ws), nb, _stream(gy)), "sprk_act_bwd")
+            out = _S.act_bwd(gy, y, ctx.act, [g.N, g.Cout, g.Hout, g.Wout], up2, want_gpre, gb)
+            gpre = out if want_gpre else gy
         else:
             gpre = gy
         if ctx.needs_input_grad[2]:
             gw = _grad_like(w)
-            nb = L.sprk_conv2d_bwd_weight_ws_bytes(ctypes.byref(g))
-            ws = _ws(nb, gy)
-            check(L.sprk_conv2d_bwd_weight(_p(x), _p(x2), _p(gpre), _p(gw), ctypes.byref(g), _p(ws), nb, _stream(x)),
-                  "sprk_conv2d_bwd_weight")
+            _S.conv2d_bwd_weight(x, x2, gpre, geom_list(g), gw)
         need0 = ctx.needs_input_grad[0]
         need1 = x2 is not None and ctx.needs_input_grad[1]
         if need0 or need1:
@@ -154,18 +141,13 @@ class _Conv2dFn(torch.autograd.Function):
                 gd = ConvGeom(g.N, g.C1, 0, g.Hin, g.Win, g.up1, g.Cout, g.Hout, g.Wout, g.KH, g.KW, g.stride, g.dil,
                               g.pad_top, g.pad_left, g.dtype)
                 wd = w[:, :g.C1].contiguous()
-            gin = torch.empty((gd.N, gd.C1 + gd.C2, gd.Hin, gd.Win), dtype=torch.float32, device=gy.device)
-            nb = L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(gd))
-            ws = _ws(nb, gy)
-            check(L.sprk_conv2d_bwd_data(_p(gpre), _p(wd), _p(gin), ctypes.byref(gd), _p(ws), nb, _stream(gpre)),
-                  "sprk_conv2d_bwd_data")
+            gin = _S.conv2d_bwd_data(gpre, wd, geom_list(gd))
             if gd.C2 == 0 and not gd.up1:
                 gx = gin
             else:
-                gx = torch.empty_like(x)
-                gx2 = torch.empty_like(x2) if gd.C2 else None
-                check(L.sprk_concat_up_bwd(_p(gin), _p(gx), _p(gx2), gd.N, gd.C1, gd.C2, gd.Hin, gd.Win, gd.up1,
-                                           _stream(gin)), "sprk_concat_up_bwd")
+                gx, gx2 = _S.concat_up_bwd(gin, gd.C1, gd.C2, gd.up1, list(x.shape), list(x2.shape) if gd.C2 else [0])
+                if not gd.C2:
+                    gx2 = None
         return gx, gx2, gw, gb, None, None, None, None, None, None, None
 
 
@@ -186,24 +168,16 @@ class _ShiftMaxPoolFn(torch.autograd.Function):
     def forward(ctx, x, shift):
         x = x.contiguous()
         _need_gpu(x)
-        N, C, H, W = x.shape
-        if H % 2 or W % 2:
-            raise ValueError("shift_maxpool2: odd spatial size %dx%d" % (H, W))
-        y = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
-        check(_lib.lib().sprk_shift_maxpool2_fwd(_p(x), _p(y), N * C, H, W, shift, _stream(x)), "sprk_shift_maxpool2_fwd")
+        if x.shape[2] % 2 or x.shape[3] % 2:
+            raise ValueError("shift_maxpool2: odd spatial size %dx%d" % (x.shape[2], x.shape[3]))
         ctx.shift = shift
         ctx.save_for_backward(x)
-        return y
+        return _S.shift_maxpool2_fwd(x, shift)
 
     @staticmethod
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
-        gy = gy.contiguous()
-        N, C, H, W = x.shape
-        gx = torch.empty_like(x)
-        check(_lib.lib().sprk_shift_maxpool2_bwd(_p(gy), _p(x), _p(gx), N * C, H, W, ctx.shift, _stream(gy)),
-              "sprk_shift_maxpool2_bwd")
-        return gx, None
+        return _S.shift_maxpool2_bwd(gy.contiguous(), x, ctx.shift), None
 
 
 def shift_maxpool2(x, shift=1):
@@ -215,20 +189,13 @@ class _Rot4Fn(torch.autograd.Function):
     def forward(ctx, x):
         x = x.contiguous()
         _need_gpu(x)
-        B, C, H, W = x.shape
-        if H != W:
-            raise ValueError("rot4_stack needs square images, got %dx%d" % (H, W))
-        y = torch.empty((4 * B, C, H, W), dtype=x.dtype, device=x.device)
-        check(_lib.lib().sprk_rot4_stack_fwd(_p(x), _p(y), B, C, H, _stream(x)), "sprk_rot4_stack_fwd")
-        return y
+        if x.shape[2] != x.shape[3]:
+            raise ValueError("rot4_stack needs square images, got %dx%d" % (x.shape[2], x.shape[3]))
+        return _S.rot4_stack_fwd(x)
 
     @staticmethod
     def backward(ctx, gy):
-        gy = gy.contiguous()
-        B4, C, P, _ = gy.shape
-        gx = torch.empty((B4 // 4, C, P, P), dtype=gy.dtype, device=gy.device)
-        check(_lib.lib().sprk_rot4_stack_bwd(_p(gy), _p(gx), B4 // 4, C, P, _stream(gy)), "sprk_rot4_stack_bwd")
-        return gx
+        return _S.rot4_stack_bwd(gy.contiguous())
 
 
 def rot4_stack(x):
@@ -240,20 +207,13 @@ class _UnrotFn(torch.autograd.Function):
     def forward(ctx, d):
         d = d.contiguous()
         _need_gpu(d)
-        B4, C, P, W = d.shape
-        if P != W or B4 % 4:
+        if d.shape[2] != d.shape[3] or d.shape[0] % 4:
             raise ValueError("unrot4_shift_concat: bad shape %s" % (tuple(d.shape),))
-        f = torch.empty((B4 // 4, 4 * C, P, P), dtype=d.dtype, device=d.device)
-        check(_lib.lib().sprk_unrot4_shift_concat_fwd(_p(d), _p(f), B4 // 4, C, P, _stream(d)), "sprk_unrot4_fwd")
-        return f
+        return _S.unrot4_shift_concat_fwd(d)
 
     @staticmethod
     def backward(ctx, gf):
-        gf = gf.contiguous()
-        B, C4, P, _ = gf.shape
-        gd = torch.empty((4 * B, C4 // 4, P, P), dtype=gf.dtype, device=gf.device)
-        check(_lib.lib().sprk_unrot4_shift_concat_bwd(_p(gf), _p(gd), B, C4 // 4, P, _stream(gf)), "sprk_unrot4_bwd")
-        return gd
+        return _S.unrot4_shift_concat_bwd(gf.contiguous())
 
 
 def unrot4_shift_concat(d):
@@ -271,51 +231,38 @@ class _BNTrainFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, groups):
         x = x.contiguous()
         _need_gpu(x, gamma, beta)
-        N, C, H, W = x.shape
+        N = x.shape[0]
         if N % groups:
             raise ValueError("batch_norm_train: batch %d is not divisible into %d groups" % (N, groups))
         Ng = N // groups
-        y = torch.empty_like(x)
-        mean = torch.empty((groups, C), dtype=torch.float32, device=x.device)
-        invstd = torch.empty((groups, C), dtype=torch.float32, device=x.device)
-        L = _lib.lib()
-        nb = L.sprk_bn_ws_bytes(Ng, C, H * W)
-        ws = _ws(nb, x)
+        ys, means, invstds = [], [], []
         for g in range(groups):
-            sl = slice(g * Ng, (g + 1) * Ng)
-            check(L.sprk_bn_train_fwd(_p(x[sl]), _p(y[sl]), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                      _p(mean[g]), _p(invstd[g]), Ng, C, H * W, momentum, eps, int(relu), _p(ws), nb,
-                                      _stream(x)), "sprk_bn_train_fwd")
+            y, m, iv = _S.bn_train_fwd(x[g * Ng:(g + 1) * Ng], gamma, beta, running_mean, running_var, momentum, eps, relu)
+            ys.append(y); means.append(m); invstds.append(iv)
+        y = ys[0] if groups == 1 else torch.cat(ys, 0)
         ctx.relu, ctx.groups = relu, groups
-        ctx.save_for_backward(x, y, gamma, mean, invstd, beta)
+        ctx.save_for_backward(x, y, gamma, torch.stack(means), torch.stack(invstds), beta)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, y, gamma, mean, invstd, beta = ctx.saved_tensors
         gy = gy.contiguous()
-        N, C, H, W = x.shape
+        N, C = x.shape[0], x.shape[1]
         groups = ctx.groups
         Ng = N // groups
-        gx = torch.empty_like(x)
         if groups == 1:     # straight into the parameters' gradient tensors
-            gg, gb = _grad_like(gamma).view(1, C), _grad_like(beta).view(1, C)
-        else:
-            gg = torch.empty((groups, C), dtype=torch.float32, device=x.device)
-            gb = torch.empty((groups, C), dtype=torch.float32, device=x.device)
-        L = _lib.lib()
-        nb = L.sprk_bn_ws_bytes(Ng, C, H * W)
-        ws = _ws(nb, x)
+            gg, gb = _grad_like(gamma), _grad_like(beta)
+            gx = _S.bn_train_bwd(gy, x, y, gamma, mean[0], invstd[0], ctx.relu, gg, gb)
+            return gx, gg, gb, None, None, None, None, None, None
+        ggs = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+        gbs = torch.empty((groups, C), dtype=torch.float32, device=x.device)
+        gxs = []
         for g in range(groups):
             sl = slice(g * Ng, (g + 1) * Ng)
-            check(L.sprk_bn_train_bwd(_p(gy[sl]), _p(x[sl]), _p(y[sl]), _p(gamma), _p(mean[g]), _p(invstd[g]),
-                                      _p(gx[sl]), _p(gg[g]), _p(gb[g]), Ng, C, H * W, int(ctx.relu), _p(ws), nb,
-                                      _stream(gy)), "sprk_bn_train_bwd")
-        if groups > 1:
-            gg, gb = torch.sum(gg, 0, out=_grad_like(gamma)), torch.sum(gb, 0, out=_grad_like(beta))
-        else:
-            gg, gb = gg.view(C), gb.view(C)
-        return gx, gg, gb, None, None, None, None, None, None
+            gxs.append(_S.bn_train_bwd(gy[sl], x[sl], y[sl], gamma, mean[g], invstd[g], ctx.relu, ggs[g], gbs[g]))
+        gg, gb = torch.sum(ggs, 0, out=_grad_like(gamma)), torch.sum(gbs, 0, out=_grad_like(beta))
+        return torch.cat(gxs, 0), gg, gb, None, None, None, None, None, None
 
 
 def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=False, groups=1):
@@ -327,11 +274,7 @@ def batch_norm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5, relu=Fa
     """Inference-only (no autograd)."""
     x = x.contiguous()
     _need_gpu(x)
-    N, C, H, W = x.shape
-    y = torch.empty_like(x)
-    check(_lib.lib().sprk_bn_eval_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                      N, C, H * W, float(eps), int(relu), _stream(x)), "sprk_bn_eval_fwd")
-    return y
+    return _S.bn_eval_fwd(x, gamma, beta, running_mean, running_var, float(eps), bool(relu))
 
 
 # ---- per-pixel pipeline maths -------------------------------------------------------------------
@@ -341,22 +284,15 @@ class _ReparamFn(torch.autograd.Function):
         out_stats = out_stats.contiguous()
         eps = eps.contiguous()
         _need_gpu(out_stats, eps)
-        B, C, H, W = out_stats.shape
-        if C != 2:
+        if out_stats.shape[1] != 2:
             raise ValueError("reparameterize expects out_stats with 2 channels")
-        z = torch.empty((B, 1, H, W), dtype=out_stats.dtype, device=out_stats.device)
-        check(_lib.lib().sprk_reparam_fwd(_p(out_stats), _p(eps), _p(z), B, H * W, _stream(out_stats)), "sprk_reparam_fwd")
         ctx.save_for_backward(out_stats, eps)
-        return z
+        return _S.reparam_fwd(out_stats, eps)
 
     @staticmethod
     def backward(ctx, gz):
         out_stats, eps = ctx.saved_tensors
-        gz = gz.contiguous()
-        B, _, H, W = out_stats.shape
-        go = torch.empty_like(out_stats)
-        check(_lib.lib().sprk_reparam_bwd(_p(gz), _p(out_stats), _p(eps), _p(go), B, H * W, _stream(gz)), "sprk_reparam_bwd")
-        return go, None
+        return _S.reparam_bwd(gz.contiguous(), out_stats, eps), None
 
 
 def reparameterize(out_stats, eps):
@@ -368,18 +304,13 @@ class _SigmoidClampFn(torch.autograd.Function):
     def forward(ctx, x):
         x = x.contiguous()
         _need_gpu(x)
-        p = torch.empty_like(x)
-        check(_lib.lib().sprk_sigmoid_clamp_fwd(_p(x), _p(p), x.numel(), _stream(x)), "sprk_sigmoid_clamp_fwd")
         ctx.save_for_backward(x)
-        return p
+        return _S.sigmoid_clamp_fwd(x)
 
     @staticmethod
     def backward(ctx, gp):
         (x,) = ctx.saved_tensors
-        gp = gp.contiguous()
-        gx = torch.empty_like(x)
-        check(_lib.lib().sprk_sigmoid_clamp_bwd(_p(gp), _p(x), _p(gx), x.numel(), _stream(gp)), "sprk_sigmoid_clamp_bwd")
-        return gx
+        return _S.sigmoid_clamp_bwd(gp.contiguous(), x)
 
 
 def sigmoid_clamp(x):
@@ -393,15 +324,7 @@ class _SsdnFn(torch.autograd.Function):
         out_stats = out_stats.contiguous()
         ns = noise_std.reshape(-1).contiguous()
         _need_gpu(x, out_stats, ns)
-        B, _, H, W = out_stats.shape
-        L = _lib.lib()
-        loss = torch.empty((B, 1), dtype=torch.float32, device=x.device)
-        pme = torch.empty((B, 1, H, W), dtype=torch.float32, device=x.device)
-        mstd = torch.empty((1, B, H, W), dtype=torch.float32, device=x.device)
-        nb = L.sprk_ssdn_ws_bytes(B, H * W)
-        ws = _ws(nb, x)
-        check(L.sprk_ssdn_fwd(_p(x), _p(out_stats), _p(ns), _p(loss), _p(pme), _p(mstd), B, H * W, _p(ws), nb, _stream(x)),
-              "sprk_ssdn_fwd")
+        loss, pme, mstd = _S.ssdn_fwd(x, out_stats, ns)
         ctx.save_for_backward(x, out_stats, ns)
         ctx.ns_shape = noise_std.shape
         ctx.mark_non_differentiable(pme, mstd)
@@ -410,15 +333,7 @@ class _SsdnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _gpme, _gmstd):
         x, out_stats, ns = ctx.saved_tensors
-        B, _, H, W = out_stats.shape
-        L = _lib.lib()
-        gl = gloss.reshape(-1).contiguous()
-        go = torch.empty_like(out_stats)
-        gns = torch.empty(B, dtype=torch.float32, device=x.device)
-        nb = L.sprk_ssdn_ws_bytes(B, H * W)
-        ws = _ws(nb, x)
-        check(L.sprk_ssdn_bwd(_p(gl), _p(x), _p(out_stats), _p(ns), _p(go), _p(gns), B, H * W, _p(ws), nb, _stream(gl)),
-              "sprk_ssdn_bwd")
+        go, gns = _S.ssdn_bwd(gloss.reshape(-1).contiguous(), x, out_stats, ns)
         return None, go, gns.reshape(ctx.ns_shape)
 
 

@@ -1,0 +1,275 @@
+"""``torch.ops.sprk.*``: the libsprk.so entry points registered as PyTorch custom operators (torch.library).
+
+One operator per C-ABI function of include/sprk.h, schema-typed, with a CUDA implementation (the ctypes call on
+torch's current stream of the tensors' device) and a fake / meta implementation (output shapes only), so the
+dispatcher, ``torch.library.opcheck``-style tooling, FakeTensor tracing and CUDA-graph capture all see them as ordinary
+operators.  Autograd is NOT registered here: ops.py's ``autograd.Function`` classes call these operators in their
+forward and backward (the backward kernels are operators too), which keeps a single place for the saved-tensor policy.
+There is no CPU implementation — dispatching a CPU tensor raises — and a missing libsprk.so raises at first use.
+
+Geometry travels as the 16 integers of ``sprk_conv_geom`` (``ConvGeom`` field order: N, C1, C2, Hin, Win, up1, Cout,
+Hout, Wout, KH, KW, stride, dil, pad_top, pad_left, dtype).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvEpilogue, ConvGeom, check
+
+_LIB = torch.library.Library("sprk", "DEF")
+_NAMES = []
+
+
+def _stream(t):
+    dev = t.device
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        raise _lib.SprkError("tensor on %s but the current device is cuda:%d — call torch.cuda.set_device(%d) "
+                             "(Denoiser / DenoiserTrainer / DenoiserEvaluator do it for their own device)"
+                             % (dev, torch.cuda.current_device(), dev.index))
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _ws(nbytes, like):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
+
+
+def _f32(like, shape):
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def _register(name, schema, impl, fake):
+    _LIB.define(name + schema)
+    _LIB.impl(name, impl, "CUDA")
+    torch.library.register_fake("sprk::" + name, fake, lib=_LIB)
+    _NAMES.append(name)
+
+
+def geom_list(g):
+    return [getattr(g, f) for f, _ in ConvGeom._fields_]
+
+
+# ---- convolution -----------------------------------------------------------------------------------------------------
+def _conv2d_fwd(x, x2, w, bias, scale, shift, res, geom, res_off, act, up_out):
+    L = _lib.lib()
+    g = ConvGeom(*geom)
+    m = 2 if up_out else 1
+    y = _f32(x, (g.N, g.Cout, g.Hout * m, g.Wout * m))
+    ep = ConvEpilogue(_p(bias), _p(scale), _p(shift), _p(res), 0 if res is None else res.shape[2],
+                      0 if res is None else res.shape[3], res_off, act, 1 if up_out else 0)
+    nb = L.sprk_conv2d_fwd_ws_bytes(ctypes.byref(g))
+    ws = _ws(nb, x)
+    check(L.sprk_conv2d_fwd(_p(x), _p(x2), _p(w), _p(y), ctypes.byref(g), ctypes.byref(ep), _p(ws), nb, _stream(x)),
+          "sprk_conv2d_fwd")
+    return y
+
+
+def _conv2d_fwd_fake(x, x2, w, bias, scale, shift, res, geom, res_off, act, up_out):
+    m = 2 if up_out else 1
+    return x.new_empty((geom[0], geom[6], geom[7] * m, geom[8] * m))
+
+
+_register("conv2d_fwd", "(Tensor x, Tensor? x2, Tensor w, Tensor? bias, Tensor? scale, Tensor? shift, Tensor? res, "
+                        "int[] geom, int res_off, int act, int up_out) -> Tensor", _conv2d_fwd, _conv2d_fwd_fake)
+
+
+def _conv2d_bwd_data(gy, w, geom):
+    L = _lib.lib()
+    g = ConvGeom(*geom)
+    gin = _f32(gy, (g.N, g.C1 + g.C2, g.Hin, g.Win))
+    nb = L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(g))
+    ws = _ws(nb, gy)
+    check(L.sprk_conv2d_bwd_data(_p(gy), _p(w), _p(gin), ctypes.byref(g), _p(ws), nb, _stream(gy)), "sprk_conv2d_bwd_data")
+    return gin
+
+
+_register("conv2d_bwd_data", "(Tensor gy, Tensor w, int[] geom) -> Tensor", _conv2d_bwd_data,
+          lambda gy, w, geom: gy.new_empty((geom[0], geom[1] + geom[2], geom[3], geom[4])))
+
+
+def _conv2d_bwd_weight(x, x2, gy, geom, gw):
+    """Out variant: writes into ``gw`` (a fresh tensor or the parameter's slice of the flat gradient buffer)."""
+    L = _lib.lib()
+    g = ConvGeom(*geom)
+    nb = L.sprk_conv2d_bwd_weight_ws_bytes(ctypes.byref(g))
+    ws = _ws(nb, gy)
+    check(L.sprk_conv2d_bwd_weight(_p(x), _p(x2), _p(gy), _p(gw), ctypes.byref(g), _p(ws), nb, _stream(x)),
+          "sprk_conv2d_bwd_weight")
+
+
+_register("conv2d_bwd_weight", "(Tensor x, Tensor? x2, Tensor gy, int[] geom, Tensor(a!) gw) -> ()", _conv2d_bwd_weight,
+          lambda x, x2, gy, geom, gw: None)
+
+
+def _act_bwd(gy, y, act, geom4, up2, want_gpre, gbias):
+    """gpre = gy * act'(y) (2x2-summed first when up2); bias gradient into ``gbias`` when given.  Returns gpre (or gy
+    itself when no new tensor is needed)."""
+    L = _lib.lib()
+    N, C, H, W = geom4
+    gpre = _f32(gy, (N, C, H, W)) if want_gpre else None
+    nb = L.sprk_act_bwd_ws_bytes(N, C, H * W)
+    ws = _ws(nb, gy)
+    check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, _p(ws), nb, _stream(gy)), "sprk_act_bwd")
+    return gpre if want_gpre else gy.new_empty(0)
+
+
+_register("act_bwd", "(Tensor gy, Tensor? y, int act, int[] nchw, int up2, bool want_gpre, Tensor(a!)? gbias) -> Tensor",
+          _act_bwd, lambda gy, y, act, nchw, up2, want_gpre, gbias: gy.new_empty(tuple(nchw) if want_gpre else (0,)))
+
+
+def _concat_up_bwd(gin, C1, C2, up1, x_shape, x2_shape):
+    L = _lib.lib()
+    N, _, H, W = gin.shape
+    gx = _f32(gin, tuple(x_shape))
+    gx2 = _f32(gin, tuple(x2_shape)) if C2 else gin.new_empty(0)
+    check(L.sprk_concat_up_bwd(_p(gin), _p(gx), _p(gx2) if C2 else None, N, C1, C2, H, W, up1, _stream(gin)),
+          "sprk_concat_up_bwd")
+    return gx, gx2
+
+
+_register("concat_up_bwd", "(Tensor gin, int C1, int C2, int up1, int[] x_shape, int[] x2_shape) -> (Tensor, Tensor)",
+          _concat_up_bwd, lambda gin, C1, C2, up1, xs, x2s: (gin.new_empty(tuple(xs)), gin.new_empty(tuple(x2s) if C2 else (0,))))
+
+
+# ---- U-Net plumbing ----------------------------------------------------------------------------------------------------
+def _simple(name, schema, cfn, out_shape, args):
+    """Register an operator whose C function takes (inputs..., output, ints..., stream)."""
+    def impl(*a):
+        L = _lib.lib()
+        tensors = [t for t in a if torch.is_tensor(t)]
+        y = _f32(tensors[0], out_shape(*a))
+        check(getattr(L, cfn)(*args(a, y), _stream(tensors[0])), cfn)
+        return y
+    _register(name, schema, impl, lambda *a: [t for t in a if torch.is_tensor(t)][0].new_empty(out_shape(*a)))
+
+
+_simple("shift_maxpool2_fwd", "(Tensor x, int shift) -> Tensor", "sprk_shift_maxpool2_fwd",
+        lambda x, shift: (x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2),
+        lambda a, y: (_p(a[0]), _p(y), a[0].shape[0] * a[0].shape[1], a[0].shape[2], a[0].shape[3], a[1]))
+_simple("shift_maxpool2_bwd", "(Tensor gy, Tensor x, int shift) -> Tensor", "sprk_shift_maxpool2_bwd",
+        lambda gy, x, shift: tuple(x.shape),
+        lambda a, y: (_p(a[0]), _p(a[1]), _p(y), a[1].shape[0] * a[1].shape[1], a[1].shape[2], a[1].shape[3], a[2]))
+_simple("rot4_stack_fwd", "(Tensor x) -> Tensor", "sprk_rot4_stack_fwd",
+        lambda x: (4 * x.shape[0], x.shape[1], x.shape[2], x.shape[3]),
+        lambda a, y: (_p(a[0]), _p(y), a[0].shape[0], a[0].shape[1], a[0].shape[2]))
+_simple("rot4_stack_bwd", "(Tensor gy) -> Tensor", "sprk_rot4_stack_bwd",
+        lambda gy: (gy.shape[0] // 4, gy.shape[1], gy.shape[2], gy.shape[3]),
+        lambda a, y: (_p(a[0]), _p(y), a[0].shape[0] // 4, a[0].shape[1], a[0].shape[2]))
+_simple("unrot4_shift_concat_fwd", "(Tensor d) -> Tensor", "sprk_unrot4_shift_concat_fwd",
+        lambda d: (d.shape[0] // 4, 4 * d.shape[1], d.shape[2], d.shape[3]),
+        lambda a, y: (_p(a[0]), _p(y), a[0].shape[0] // 4, a[0].shape[1], a[0].shape[2]))
+_simple("unrot4_shift_concat_bwd", "(Tensor gf) -> Tensor", "sprk_unrot4_shift_concat_bwd",
+        lambda gf: (4 * gf.shape[0], gf.shape[1] // 4, gf.shape[2], gf.shape[3]),
+        lambda a, y: (_p(a[0]), _p(y), a[0].shape[0], a[0].shape[1] // 4, a[0].shape[2]))
+
+# ---- per-pixel pipeline maths ----------------------------------------------------------------------------------------------
+_simple("reparam_fwd", "(Tensor out_stats, Tensor eps) -> Tensor", "sprk_reparam_fwd",
+        lambda o, e: (o.shape[0], 1, o.shape[2], o.shape[3]),
+        lambda a, y: (_p(a[0]), _p(a[1]), _p(y), a[0].shape[0], a[0].shape[2] * a[0].shape[3]))
+_simple("reparam_bwd", "(Tensor gz, Tensor out_stats, Tensor eps) -> Tensor", "sprk_reparam_bwd",
+        lambda gz, o, e: tuple(o.shape),
+        lambda a, y: (_p(a[0]), _p(a[1]), _p(a[2]), _p(y), a[1].shape[0], a[1].shape[2] * a[1].shape[3]))
+_simple("sigmoid_clamp_fwd", "(Tensor x) -> Tensor", "sprk_sigmoid_clamp_fwd", lambda x: tuple(x.shape),
+        lambda a, y: (_p(a[0]), _p(y), a[0].numel()))
+_simple("sigmoid_clamp_bwd", "(Tensor gp, Tensor x) -> Tensor", "sprk_sigmoid_clamp_bwd", lambda gp, x: tuple(x.shape),
+        lambda a, y: (_p(a[0]), _p(a[1]), _p(y), a[1].numel()))
+
+
+def _ssdn_fwd(x, out_stats, noise_std):
+    L = _lib.lib()
+    B, _, H, W = out_stats.shape
+    loss, pme, mstd = _f32(x, (B, 1)), _f32(x, (B, 1, H, W)), _f32(x, (1, B, H, W))
+    nb = L.sprk_ssdn_ws_bytes(B, H * W)
+    ws = _ws(nb, x)
+    check(L.sprk_ssdn_fwd(_p(x), _p(out_stats), _p(noise_std), _p(loss), _p(pme), _p(mstd), B, H * W, _p(ws), nb,
+                          _stream(x)), "sprk_ssdn_fwd")
+    return loss, pme, mstd
+
+
+def _ssdn_fwd_fake(x, out_stats, noise_std):
+    B, _, H, W = out_stats.shape
+    return x.new_empty((B, 1)), x.new_empty((B, 1, H, W)), x.new_empty((1, B, H, W))
+
+
+_register("ssdn_fwd", "(Tensor x, Tensor out_stats, Tensor noise_std) -> (Tensor, Tensor, Tensor)", _ssdn_fwd, _ssdn_fwd_fake)
+
+
+def _ssdn_bwd(gloss, x, out_stats, noise_std):
+    L = _lib.lib()
+    B, _, H, W = out_stats.shape
+    go, gns = torch.empty_like(out_stats), _f32(x, (B,))
+    nb = L.sprk_ssdn_ws_bytes(B, H * W)
+    ws = _ws(nb, x)
+    check(L.sprk_ssdn_bwd(_p(gloss), _p(x), _p(out_stats), _p(noise_std), _p(go), _p(gns), B, H * W, _p(ws), nb,
+                          _stream(x)), "sprk_ssdn_bwd")
+    return go, gns
+
+
+_register("ssdn_bwd", "(Tensor gloss, Tensor x, Tensor out_stats, Tensor noise_std) -> (Tensor, Tensor)", _ssdn_bwd,
+          lambda gl, x, o, ns: (torch.empty_like(o), x.new_empty((o.shape[0],))))
+
+
+# ---- BatchNorm -----------------------------------------------------------------------------------------------------------
+def _bn_eval_fwd(x, gamma, beta, running_mean, running_var, eps, relu):
+    N, C, H, W = x.shape
+    y = torch.empty_like(x)
+    check(_lib.lib().sprk_bn_eval_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var), N, C, H * W,
+                                      float(eps), int(relu), _stream(x)), "sprk_bn_eval_fwd")
+    return y
+
+
+_register("bn_eval_fwd", "(Tensor x, Tensor gamma, Tensor beta, Tensor running_mean, Tensor running_var, float eps, "
+                         "bool relu) -> Tensor", _bn_eval_fwd, lambda x, *a: torch.empty_like(x))
+
+
+def _bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    """One BatchNorm group: returns (y, save_mean, save_invstd); updates the running statistics in place."""
+    L = _lib.lib()
+    N, C, H, W = x.shape
+    y, mean, invstd = torch.empty_like(x), _f32(x, (C,)), _f32(x, (C,))
+    nb = L.sprk_bn_ws_bytes(N, C, H * W)
+    ws = _ws(nb, x)
+    check(L.sprk_bn_train_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(mean), _p(invstd),
+                              N, C, H * W, momentum, eps, int(relu), _p(ws), nb, _stream(x)), "sprk_bn_train_fwd")
+    return y, mean, invstd
+
+
+_register("bn_train_fwd", "(Tensor x, Tensor gamma, Tensor beta, Tensor(a!) running_mean, Tensor(b!) running_var, "
+                          "float momentum, float eps, bool relu) -> (Tensor, Tensor, Tensor)", _bn_train_fwd,
+          lambda x, g, *a: (torch.empty_like(x), g.new_empty(g.shape), g.new_empty(g.shape)))
+
+
+def _bn_train_bwd(gy, x, y, gamma, mean, invstd, relu, ggamma, gbeta):
+    L = _lib.lib()
+    N, C, H, W = x.shape
+    gx = torch.empty_like(x)
+    nb = L.sprk_bn_ws_bytes(N, C, H * W)
+    ws = _ws(nb, x)
+    check(L.sprk_bn_train_bwd(_p(gy), _p(x), _p(y), _p(gamma), _p(mean), _p(invstd), _p(gx), _p(ggamma), _p(gbeta),
+                              N, C, H * W, int(relu), _p(ws), nb, _stream(x)), "sprk_bn_train_bwd")
+    return gx
+
+
+_register("bn_train_bwd", "(Tensor gy, Tensor x, Tensor y, Tensor gamma, Tensor mean, Tensor invstd, bool relu, "
+                          "Tensor(a!) ggamma, Tensor(b!) gbeta) -> Tensor", _bn_train_bwd,
+          lambda gy, x, *a: torch.empty_like(x))
+
+
+# ---- NMS (one relaxation call; algorithms.nms_device drives the fixed point) -------------------------------------------------
+def _nms2d(score, r, threshold, out_s, out_xy, cnt, rounds, resume, ws):
+    H, W = score.shape
+    check(_lib.lib().sprk_nms2d(_p(score), H, W, int(r), ctypes.c_float(threshold), _p(out_s), _p(out_xy), _p(cnt),
+                                out_s.shape[0], rounds, resume, _p(ws), ws.numel(), _stream(score)), "sprk_nms2d")
+
+
+_register("nms2d", "(Tensor score, int r, float threshold, Tensor(a!) out_s, Tensor(b!) out_xy, Tensor(c!) cnt, "
+                   "int rounds, int resume, Tensor(d!) ws) -> ()", _nms2d, lambda *a: None)
+
+
+def registered():
+    """Names of the operators under torch.ops.sprk (tests)."""
+    return tuple(_NAMES)

@@ -57,3 +57,33 @@ def test_product_package_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oracle/" not in src or f == "denoiser.py", f
+
+
+def test_torch_library_registration_and_fake_shapes():
+    """Every C entry point of the hot path is a PyTorch custom operator (torch.ops.sprk.*) with a fake implementation:
+    shape propagation works without a GPU and without touching libsprk.so."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from spr_pick_amd import ops, torch_ops
+    names = set(torch_ops.registered())
+    assert {"conv2d_fwd", "conv2d_bwd_data", "conv2d_bwd_weight", "act_bwd", "shift_maxpool2_fwd", "rot4_stack_fwd",
+            "unrot4_shift_concat_fwd", "bn_train_fwd", "bn_train_bwd", "bn_eval_fwd", "reparam_fwd", "sigmoid_clamp_fwd",
+            "ssdn_fwd", "ssdn_bwd", "nms2d"} <= names
+    for n in names:
+        assert hasattr(torch.ops.sprk, n)
+    with FakeTensorMode():
+        x = torch.empty(4, 48, 64, 64, device="cuda")
+        w = torch.empty(96, 48, 3, 3, device="cuda")
+        g = ops.make_geom(x, None, w, False, 1, 1, (2, 0, 1, 1))
+        y = torch.ops.sprk.conv2d_fwd(x, None, w, None, None, None, None, torch_ops.geom_list(g), 0, 1, 1)
+        assert tuple(y.shape) == (4, 96, 128, 128)          # fused 2x upsampling store
+        assert tuple(torch.ops.sprk.conv2d_bwd_data(torch.empty(4, 96, 64, 64, device="cuda"), w,
+                                                    torch_ops.geom_list(g)).shape) == (4, 48, 64, 64)
+        assert tuple(torch.ops.sprk.shift_maxpool2_fwd(x, 1).shape) == (4, 48, 32, 32)
+        assert tuple(torch.ops.sprk.rot4_stack_fwd(torch.empty(2, 1, 8, 8, device="cuda")).shape) == (8, 1, 8, 8)
+        assert tuple(torch.ops.sprk.unrot4_shift_concat_fwd(torch.empty(8, 96, 8, 8, device="cuda")).shape) == (2, 384, 8, 8)
+    # CPU tensors: no CPU kernel is registered, the functional API refuses them up front
+    import pytest
+    from spr_pick_amd import _lib
+    with pytest.raises(_lib.SprkError):
+        ops.shift_maxpool2(torch.zeros(1, 1, 4, 4))

@@ -483,3 +483,23 @@ def test_joint_train_step_16bit_operands(denoiser, oracle_state, dt):
     assert all(v <= budget["out"] for v in model_err.values()), model_err
     assert all(v <= budget["out"] for v in ref_err.values()), ref_err
     assert cos_min >= budget["cos"] and norm_dev <= budget["norm"], (cos_min, norm_dev)
+
+
+def test_nms_with_seeded_contam_set():
+    """The reference's `contam` argument (utils/algorithms.py:77,98-101): pre-suppressed indices are skipped, the set is
+    extended by everything the picks suppress — against the literal oracle walk, picks and final set identical."""
+    from oracle import nms
+    from spr_pick_amd import non_maximum_suppression
+    rng = np.random.default_rng(5)
+    x = rng.random((96, 80), dtype=np.float32)
+    seed = set(int(v) for v in rng.integers(0, 96 * 80, size=400)) | {96 * 80 + 3}     # incl. one past-the-end index
+    mine, ref = set(seed), set(seed)
+    s, c = non_maximum_suppression(x, 6, mine, 0.3)
+    s2, c2 = nms.nms_literal(x, 6, 0.3, contam=ref)
+    assert len(s) > 10 and np.array_equal(c, c2) and np.array_equal(s, s2)
+    assert mine == ref
+    flat = c[:, 1].astype(np.int64) * 80 + c[:, 0]
+    assert not (set(flat.tolist()) & seed)
+    empty = set()
+    non_maximum_suppression(x, 6, empty, 0.3)
+    assert empty == set()      # an empty set is left alone (documented; algorithms.UPDATE_EMPTY_CONTAM)
