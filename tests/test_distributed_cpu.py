@@ -74,3 +74,53 @@ def test_single_process_is_a_noop():
     before = lin.weight.grad.clone()
     distributed.FlatGradAllReduce(lin.parameters(), 1)()
     assert torch.equal(before, lin.weight.grad)
+
+
+def test_eval_sharding_three_ranks_seven_micrographs():
+    """Inference shards micrograph i -> rank i % world with no collective: over 3 ranks and 7 micrographs
+    the per-rank evaluation feeds are disjoint, complete and keep dataset order; a count above the dataset length wraps
+    as the reference's sequential sampler does."""
+    import numpy as np
+    from spr_pick_amd import feed
+    from spr_pick_amd.datasets import DetectionDataset
+    rng = np.random.default_rng(0)
+    groups = [[(rng.integers(0, 255, size=(40, 48)).astype(np.uint8), None, np.zeros((40, 48), np.float32)) for _ in range(7)]]
+    names = [["mic%d" % i for i in range(7)]]
+    seen = []
+    for rank in range(3):
+        f = feed.MicrographFeed(groups, names, count=7, device="cpu", rank=rank, world=3)
+        mine = [data[DetectionDataset.METADATA][DetectionDataset.Metadata.NAME][0] for _, data in f]
+        assert mine == ["mic%d" % i for i in range(rank, 7, 3)]
+        assert len(f) == len(mine)
+        seen += mine
+    assert sorted(seen) == sorted(names[0])
+    wrapped = feed.MicrographFeed(groups, names, count=9, device="cpu", rank=0, world=1)
+    assert [d[DetectionDataset.METADATA][DetectionDataset.Metadata.NAME][0] for _, d in wrapped] == \
+        ["mic%d" % (i % 7) for i in range(9)]
+
+
+def test_init_from_env_binds_local_rank_to_its_gpu(monkeypatch):
+    """One process per GPU over RCCL: with backend "nccl" the process must select cuda:LOCAL_RANK BEFORE the process
+    group is created (RCCL binds communicators to the current device), with the rendezvous on 127.0.0.1 by default;
+    with gloo on a box with fewer GPUs than ranks the local index wraps."""
+    from spr_pick_amd import distributed
+    calls = []
+    monkeypatch.setenv("WORLD_SIZE", "8"); monkeypatch.setenv("RANK", "5"); monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.delenv("MASTER_ADDR", raising=False); monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.delenv("SPRK_DIST_BACKEND", raising=False)
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.append(("set_device", d)))
+    monkeypatch.setattr(dist, "init_process_group", lambda **kw: calls.append(("init", kw)))
+    rank, world, local = distributed.init_from_env()
+    assert (rank, world, local) == (5, 8, 5)
+    assert calls[0] == ("set_device", 5) and calls[1][0] == "init"
+    assert calls[1][1] == {"backend": "nccl", "rank": 5, "world_size": 8}
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1"
+    # gloo rehearsal on a 1-GPU box: LOCAL_RANK 5 wraps onto device 0
+    calls.clear()
+    monkeypatch.setenv("SPRK_DIST_BACKEND", "gloo")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    rank, world, local = distributed.init_from_env()
+    assert local == 0 and calls[0][1]["backend"] == "gloo"
