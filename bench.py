@@ -362,9 +362,9 @@ def main():
                   "unit": "patches/s", "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
                   "final_loss": float(torch.mean(o2[P.LOSS].detach())),
                   "conv_layers_requesting_16bit": n16, "conv_launches_on_16bit_kernels_per_step": c16_per_step,
-                  "note": "same step, U-Net MFMA operands rounded to %s (fp32 tensors, master weights, accumulation; "
-                          "backward-weight still on the fp32 kernels); the library takes the 16-bit kernel where it "
-                          "is the faster one" % args.also_dtype}
+                  "note": "same step, U-Net MFMA operands rounded to %s in forward, backward-data and backward-weight (fp32 "
+                          "tensors, master weights, accumulation); layers the 16-bit kernels do not cover (1x1 backward-"
+                          "weight, planes below 32x32, the detector, the output convolutions) run fp32" % args.also_dtype}
         del o2, st2
         den.set_conv_dtype(args.dtype)
 

@@ -130,6 +130,19 @@ def set_lr(optimizer, lr):
             group["lr"] = lr
 
 
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """ONE side stream per device for every GraphedTrainStep of the process: autograd keeps a parameter's
+    AccumulateGrad node (and the stream it was born on) alive as long as any earlier autograd graph or captured
+    graph references it, so a second stepper on the same model (bench.py's bf16 leg) must use the same stream."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(dev)
+    return _SIDE[key]
+
+
 class GraphedTrainStep:
     """``step(inp, target) -> outputs`` with the forward + backward replayed from a HIP graph.
 
@@ -148,7 +161,7 @@ class GraphedTrainStep:
         self.tgt = torch.full((batch, 1), -1.0, dtype=torch.float32, device=self.dev)
         self._tgt_ring = PinnedRing((batch, 1), torch.float32, self.dev)
         self._empty = torch.zeros(0, device=self.dev)
-        self._side = torch.cuda.Stream(self.dev)      # every forward+backward of this object runs (or is captured) here
+        self._side = _side_stream(self.dev)           # every forward+backward runs (or is captured) on this stream
         self._graphs = {}
         self._pool = None
         self._warm = eager_warmup
