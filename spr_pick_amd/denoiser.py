@@ -174,12 +174,51 @@ class Denoiser(nn.Module):
             return t
         return t.detach().float().pin_memory().to(self.device, non_blocking=True)
 
+    def _tiled_networks(self, inp, eps, tile, halo):
+        """Halo-tiled evaluation of the two networks of the filled pipeline: the micrograph is cut
+        into interior blocks of ``tile`` pixels, each evaluated inside a square window of tile + 2*halo pixels (shifted
+        inwards at the image borders, so a window edge is either >= halo away from the block or IS the image edge),
+        and only the block is kept.  Peak memory follows the window, not the micrograph (4096^2 whole: 82 GB; windows
+        of 2944^2: 42 GB) at the price of evaluating the halos (2.07x the pixels at tile 2048).  ``halo`` must cover
+        the receptive field of blind-spot U-Net + detector; 448 is what tests/test_gpu_pipeline.py validates
+        (tiled == whole to 2e-5).  Everything after the networks (likelihood, posterior mean, sigmoid, NMS) runs on
+        the assembled full-size tensors exactly as in the whole-image path, incl. the GLOBAL mean behind noise_std.
+        Returns (net_out [1,2,H,W], detector logits [1,1,H,W], noise_std [1,1,1,1])."""
+        B, _, H, W = inp.shape
+        S = tile + 2 * halo
+        if tile % 32 or halo % 32 or H % 32 or W % 32:
+            raise ValueError("tiled inference needs tile, halo and the image size to be multiples of 32")
+        if H < S or W < S:
+            raise ValueError("image %dx%d is smaller than one window (%d): evaluate it whole" % (H, W, S))
+        model, sigma = self.models[Denoiser.MODEL], self.models[Denoiser.SIGMA_ESTIMATOR]
+        if eps is None:
+            eps = torch.randn((B, 1, H, W), dtype=inp.dtype, device=inp.device)
+        net_out = torch.empty((B, 2, H, W), dtype=torch.float32, device=inp.device)
+        logits = torch.empty((B, 1, H, W), dtype=torch.float32, device=inp.device)
+        est = torch.empty((B, 1, H, W), dtype=torch.float32, device=inp.device)
+        for y0 in range(0, H, tile):
+            y1 = min(y0 + tile, H)
+            wy = min(max(y0 - halo, 0), H - S)
+            for x0 in range(0, W, tile):
+                x1 = min(x0 + tile, W)
+                wx = min(max(x0 - halo, 0), W - S)
+                win = inp[:, :, wy:wy + S, wx:wx + S].contiguous()
+                o, d = model(win, eps=eps[:, :, wy:wy + S, wx:wx + S].contiguous())
+                e = sigma(win)
+                iy, ix = slice(y0 - wy, y1 - wy), slice(x0 - wx, x1 - wx)
+                net_out[:, :, y0:y1, x0:x1] = o[:, :, iy, ix]
+                logits[:, :, y0:y1, x0:x1] = d[:, :, iy, ix]
+                est[:, :, y0:y1, x0:x1] = e[:, :, iy, ix]
+                del o, d, e, win
+        noise_std = torch.nn.functional.softplus(torch.mean(est, dim=(2, 3), keepdim=True) - 4.0) + 1e-3
+        return net_out, logits, noise_std
+
     def _check_style(self):
         style = self.cfg[ConfigValue.NOISE_STYLE]
         if style is None or not style.startswith("gauss"):
             raise NotImplementedError("only the gaussian likelihood branch (--noise_style gauss*) is on the hot path")
 
-    def _new_pipeline(self, data, alpha, tau, train, eps=None, eps_flip=None, flip_p=None, **kwargs):
+    def _new_pipeline(self, data, alpha, tau, train, eps=None, eps_flip=None, flip_p=None, tile=None, halo=448, **kwargs):
         if not len(data) > 2:
             return None  # as the reference: the joint pipeline needs the full batch list (denoiser_v2.py:261)
         self._check_style()
@@ -199,12 +238,16 @@ class Denoiser(nn.Module):
             hm_p = _sigmoid(hm_p)
             hm_p_f = _sigmoid(hm_p_f.flip(axis))
             pred_loss = self._pu(tau, hm_p, self._labels_on_device(target))
+        elif tile:
+            net_out, hm_p, noise_std = self._tiled_networks(inp, eps, int(tile), int(halo))
+            hm_p = _sigmoid(hm_p)
         else:
             net_out, hm_p = model(inp, eps=eps)
             hm_p = _sigmoid(hm_p)
 
         mu_x = net_out[:, 0:1]
-        noise_std = self._noise_std(inp)
+        if not (tile and not train):
+            noise_std = self._noise_std(inp)
         loss_out, pme_out, net_std_out = ops.ssdn_nll_pme(inp, net_out, noise_std)
         if train:
             consis_loss = torch.nn.functional.mse_loss(hm_p, hm_p_f)

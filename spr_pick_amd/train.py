@@ -230,7 +230,7 @@ class DenoiserTrainer:
             eval_history = self.state[StateValue.HISTORY][HistoryValue.EVAL]
             for idx, data in feed:
                 image_count = data[DetectionDataset.INPUT].shape[0]
-                outputs = self.denoiser.run_pipeline(data, train=False)
+                outputs = self.denoiser.run_pipeline(data, train=False, tile=self._eval_tile(data[DetectionDataset.INPUT]))
                 eval_history["n"] += image_count
                 clean = outputs[PipelineOutput.INPUTS][DetectionDataset.METADATA][DetectionDataset.Metadata.GT]
                 if len(clean) > 0:   # PSNR against the clean reference images (train.py:404-413)
@@ -239,6 +239,22 @@ class DenoiserTrainer:
                 if output_callback:
                     output_callback(idx, outputs)
         self.denoiser.unfill()
+
+    BYTES_PER_PIXEL_WHOLE = 4900     # peak HBM of the whole-image filled pipeline per input pixel (82 GB at 4096^2)
+
+    def _eval_tile(self, inp):
+        """Interior block size for halo-tiled evaluation, or None for the whole-image path: SPRK_EVAL_TILE forces it
+        (0 = never); otherwise tiles of 2048 are used when the whole-image working set would not fit in 80 % of the
+        free HBM (e.g. 8192^2 micrographs: 330 GB)."""
+        H, W = int(inp.shape[-2]), int(inp.shape[-1])
+        env = os.environ.get("SPRK_EVAL_TILE")
+        if env is not None:
+            t = int(env)
+            return t if t > 0 and min(H, W) >= t + 2 * 448 else None
+        if self.mode != "joint" or min(H, W) < 2048 + 2 * 448:
+            return None
+        free, _ = torch.cuda.mem_get_info(self.device)
+        return 2048 if H * W * self.BYTES_PER_PIXEL_WHOLE > 0.8 * free else None
 
     def img_outputs(self, prefix=None):
         """Image outputs of the configured pipeline -> metric names (train.py:763-779)."""
