@@ -379,6 +379,15 @@ def main():
             torch.cuda.reset_peak_memory_stats(dev)
             infer_large = inference_leg(den, dev, args.infer_large, reps=3)
             infer_large["workload"] = "BASELINE configs[2]: one of the 128 synthetic 4096x4096 micrographs per repetition"
+            if args.also_dtype != "none":
+                # same leg with 16-bit MFMA operands in the U-Nets (fp16 for inference: 8x finer than bf16, range is no
+                # issue in the forward pass); picks are then no longer bit-identical to the fp32 path
+                den.set_conv_dtype("f16")
+                torch.cuda.reset_peak_memory_stats(dev)
+                i16 = inference_leg(den, dev, args.infer_large, reps=3)
+                den.set_conv_dtype(args.dtype)
+                infer_large["f16_operands"] = {k: i16[k] for k in ("value", "unit", "ms_per_micrograph", "network_ms", "picks",
+                                                                    "peak_hbm_gb")}
 
     if rank != 0:
         return

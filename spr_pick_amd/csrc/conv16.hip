@@ -520,6 +520,131 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
     }
 }
 
+// =====================================================================================================================
+// conv16_head_kernel: the wide 1x1 layers (384 -> up to 384 channels: the blind-spot U-Net's output block).
+// conv16_mfma_kernel gives every 96-channel output block its own workgroup, so the 384-channel input tile is staged
+// four times (and in fp32).  Here ONE workgroup computes all output channels of 128 consecutive pixels: 8 waves =
+// 2 pixel halves x 4 output-channel quarters (64 pixels x 96 channels each, 96 accumulator registers), the input is
+// fetched once HBM -> registers (8 channels of one pixel per lane, consecutive lanes on consecutive pixels), converted
+// and written channel-innermost [8-channel group][pixel][8 x 16 bit]; the weight chunk (64 input channels x 384 outputs,
+// 48 KB as 16 bit) comes from L2 by LDS-DMA.  Two k-steps (64 channels) per barrier, double buffered.
+// =====================================================================================================================
+struct Head16Args {
+    const float *x;      // [N][Cin][HW]
+    const void *w16;     // [chunks][8 groups][384][8]  (weight_transform16_kernel with CK = 64, G4 = 8, NT16 = 384)
+    const float *bias, *scale, *shift;
+    float *y;            // [N][Cout][HW]
+    int N, Cin, Cout, HW, act, nchunks, tilesPerImage;
+};
+
+constexpr int kHeadCK = 64, kHeadPx = 128, kHeadCoutP = 384;
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv16_head_kernel(const Head16Args a) {
+    using V8 = typename Op16<T>::v8;
+    typedef const __attribute__((address_space(3))) V8 *lds_v8p;
+    typedef __attribute__((address_space(3))) V8 *lds_v8w;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int inBytes = 8 * kHeadPx * 16, wBytes = 8 * kHeadCoutP * 16, stageBytes = inBytes + wBytes;
+    const int lds0 = lds_addr(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int pg = wave >> 2, cq = wave & 3;                    // pixel half, output-channel quarter
+    const int tile = blockIdx.x;
+    const int n = tile / a.tilesPerImage, p0 = (tile - n * a.tilesPerImage) * kHeadPx;
+    // fetch items: thread -> (channel group cg = 0..7 of the chunk, pixel): two items per thread (cg, cg + 4)
+    const int fpx = tid & (kHeadPx - 1), fcg = tid >> 7;        // fcg 0..3 (wave-uniform), items fcg and fcg + 4
+    const bool pok = p0 + fpx < a.HW;
+    const int voff = pok ? (p0 + fpx) * 4 : (int)0x80000000;
+    float f[2][8];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // buffer based at the 8-channel group (wave-uniform): the scalar channel offset stays below 2^31 on 4096^2 planes
+            const int ch0 = chunk * kHeadCK + (fcg + 4 * h) * 8;
+            const rsrc_t rx = make_rsrc(a.x + ((long)n * a.Cin + ch0) * a.HW);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned v = 0;
+                if (ch0 + j < a.Cin) v = __builtin_amdgcn_raw_buffer_load_b32(rx, voff, j * a.HW * 4, 0);
+                f[h][j] = __builtin_bit_cast(float, v);
+            }
+        }
+    };
+    auto convert_store = [&](int b) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            V8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (T)f[h][j];
+            *(lds_v8w)(__SIZE_TYPE__)(unsigned)(lds0 + b * stageBytes + ((fcg + 4 * h) * kHeadPx + fpx) * 16) = v;
+        }
+    };
+    auto weights = [&](int chunk, int b) {
+        const rsrc_t wr = make_rsrc(reinterpret_cast<const float *>(a.w16) + (long)chunk * (wBytes >> 2));
+        float *w_lds = smem + ((b * stageBytes + inBytes) >> 2);
+        constexpr int total16 = wBytes >> 4;                    // 3072 pieces of 16 bytes = 48 wave instructions
+        for (int gi = wave; gi * 64 < total16; gi += 8) bdma16(wr, lane * 16, gi * 1024, w_lds + gi * 256);
+    };
+    f32x4 acc[4][6];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // A: [group][pixel][8]: lane (pixel l15 of tile mt, quarter lq -> group 4 ks + lq);  B: [group][cout][8]
+    const int abase = lds0 + (lq * kHeadPx + pg * 64 + l15) * 16;
+    const int bbase = lds0 + inBytes + (lq * kHeadCoutP + cq * 96 + l15) * 16;
+    fetch(0);
+    weights(0, 0);
+    convert_store(0);
+    for (int c = 0; c < a.nchunks; ++c) {
+        __syncthreads();
+        const bool more = c + 1 < a.nchunks;
+        if (more) {
+            fetch(c + 1);
+            weights(c + 1, (c + 1) & 1);
+        }
+        const int sb = (c & 1) * stageBytes;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            V8 av[4], bv[6];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                av[mt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(abase + sb + ks * 4 * kHeadPx * 16 + mt * 256);
+#pragma unroll
+            for (int nt = 0; nt < 6; ++nt)
+                bv[nt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(bbase + sb + ks * 4 * kHeadCoutP * 16 + nt * 256);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = Op16<T>::mma(av[mt], bv[nt], acc[mt][nt]);
+        }
+        if (more) convert_store((c + 1) & 1);
+    }
+    // epilogue: D layout col(n) = lane & 15 -> output channel, row(m) = (lane >> 4) * 4 + reg -> 4 consecutive pixels
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+        const int co = cq * 96 + nt * 16 + l15;
+        if (co >= a.Cout) continue;
+        float sc = 1.f, sh = 0.f;
+        if (a.scale) {
+            sc = a.scale[co];
+            sh = a.shift[co];
+        } else if (a.bias) {
+            sh = a.bias[co];
+        }
+        float *yc = a.y + ((long)n * a.Cout + co) * a.HW + p0 + pg * 64 + lq * 4;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            if (p0 + pg * 64 + mt * 16 + lq * 4 >= a.HW) continue;      // HW % 4 == 0: a quad is all in or all out
+            const f32x4 c4 = acc[mt][nt];
+            *reinterpret_cast<float4 *>(yc + mt * 16) = make_float4(apply_act(c4[0] * sc + sh, a.act), apply_act(c4[1] * sc + sh, a.act),
+                                                                    apply_act(c4[2] * sc + sh, a.act), apply_act(c4[3] * sc + sh, a.act));
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
 constexpr size_t kLdsBudget16 = 78 * 1024;   // two workgroups per CU
 
@@ -674,6 +799,14 @@ static int plan_of(const Conv16Call &c, Plan16 *p, PlanT *pt) {
     if (c.stride != 1 || c.dil != 1 || c.up1 || c.res) return 0;
     if (c.Hout != c.Hin || c.Wout != c.Win) return 0;                 // same-size layers (U-Net body)
     if (c.padL < 0 || c.padL > 4 || c.padT < 0) return 0;
+    if (c.KH == 1 && c.KW == 1 && !c.C2 && !c.up2 && c.padT == 0 && c.padL == 0) {
+        // conv16_head_kernel: 193..384 output channels, input channels a multiple of 64, planes of 4k pixels
+        static const int head_on = getenv("SPRK_CONV16_HEAD") ? atoi(getenv("SPRK_CONV16_HEAD")) : 1;   // debug
+        const long HW = (long)c.Hin * c.Win;
+        if (head_on && c.Cout > 192 && c.Cout <= kHeadCoutP && c.C1 % kHeadCK == 0 && HW % 4 == 0 &&
+            8 * HW * 4 < (1L << 31) && (long)c.N * cdiv(HW, kHeadPx) >= 256)
+            return 3;
+    }
     if (c.KH == 3 && c.KW == 3) {
         static const int tile_on = getenv("SPRK_CONV16_TILE") ? atoi(getenv("SPRK_CONV16_TILE")) : 1;   // debug
         if (tile_on && plan_tile(c.N, c.C1 + c.C2, c.Cout, c.Hout, c.Wout, pt)) {
@@ -704,6 +837,7 @@ size_t conv16_ws_bytes(const Conv16Call &c) {
     Plan16 p;
     PlanT pt;
     const int which = plan_of(c, &p, &pt);
+    if (which == 3) return (size_t)(c.C1 / kHeadCK) * 8 * kHeadCoutP * 16 + 512;
     return which == 2 ? pt.wsBytes + 512 : which == 1 ? p.wsBytes + 512 : 0;
 }
 
@@ -755,11 +889,56 @@ static int run_tile(const Conv16Call &c, const PlanT &p, const float *x, const f
     return check_launch("conv16_tile");
 }
 
+static int run_head(const Conv16Call &c, const float *x, const float *w, float *y, void *ws, size_t ws_bytes,
+                    hipStream_t s) {
+    const int nchunks = c.C1 / kHeadCK;
+    const size_t need = (size_t)nchunks * 8 * kHeadCoutP * 16;
+    if (ws_bytes < need || !ws) {
+        set_error("conv16: workspace too small (%zu < %zu)", ws_bytes, need);
+        return SPRK_EWORKSPACE;
+    }
+    if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)ws) & 15) != 0) {
+        set_error("conv16: tensors must be 16-byte aligned");
+        return SPRK_EINVAL;
+    }
+    const int dt = c.dtype & SPRK_DT_MASK;
+    const long total = (long)nchunks * 8 * kHeadCoutP * 8;
+    const int wCout = c.mode == 0 ? c.Cout : c.C1, wCin = c.mode == 0 ? c.C1 : c.Cout;
+    if (dt == SPRK_DT_BF16)
+        hipLaunchKernelGGL(weight_transform16_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (__bf16 *)ws,
+                           wCout, wCin, 1, c.mode, kHeadCK, 8, kHeadCoutP, 1, nchunks);
+    else
+        hipLaunchKernelGGL(weight_transform16_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (_Float16 *)ws,
+                           wCout, wCin, 1, c.mode, kHeadCK, 8, kHeadCoutP, 1, nchunks);
+    if (int rc = check_launch("weight_transform16")) return rc;
+    Head16Args a{};
+    a.x = x; a.w16 = ws; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift; a.y = y;
+    a.N = c.N; a.Cin = c.C1; a.Cout = c.Cout; a.HW = c.Hin * c.Win; a.act = c.act; a.nchunks = nchunks;
+    a.tilesPerImage = cdiv(a.HW, kHeadPx);
+    const size_t lds = 2 * (size_t)(8 * kHeadPx * 16 + 8 * kHeadCoutP * 16);
+    auto go = [&](auto kernel) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            set_error("conv16: cannot reserve %zu bytes of LDS", lds);
+            return (int)SPRK_ELAUNCH;
+        }
+        hipLaunchKernelGGL(kernel, dim3(c.N * a.tilesPerImage), dim3(512), lds, s, a);
+        return (int)SPRK_OK;
+    };
+    prof_begin(c.kclass, c.flops, s);
+    const int rc = dt == SPRK_DT_BF16 ? go(conv16_head_kernel<__bf16>) : go(conv16_head_kernel<_Float16>);
+    if (rc) return rc;
+    prof_end(c.kclass, s);
+    g_conv16_launches.fetch_add(1, std::memory_order_relaxed);
+    return check_launch("conv16_head");
+}
+
 int conv16_run(const Conv16Call &c, const float *x, const float *x2, const float *w, float *y, void *ws, size_t ws_bytes,
                hipStream_t s) {
     Plan16 p;
     PlanT pt;
     const int which = plan_of(c, &p, &pt);
+    if (which == 3) return run_head(c, x, w, y, ws, ws_bytes, s);
     if (which == 2) return run_tile(c, pt, x, x2, w, y, ws, ws_bytes, s);
     if (which == 0) {
         set_error("conv16: geometry not eligible");

@@ -395,6 +395,8 @@ CONV16_CASES = [
     ("c16 sigma plain 96+1->96 @64", 4, 96, 1, 64, 64, 96, 3, (1, 1, 1, 1), 1, True, False),
     ("c16 dec1.2 shift 96->96 @64", 8, 96, 0, 64, 64, 96, 3, (2, 0, 1, 1), 1, True, False),
     ("c16 head 1x1 384->384 @64", 4, 384, 0, 64, 64, 384, 1, (0, 0, 0, 0), 1, True, False),
+    ("c16 head kernel 1x1 384->384 @64 (all outputs per workgroup)", 8, 384, 0, 64, 64, 384, 1, (0, 0, 0, 0), 1, True, False),
+    ("c16 head kernel 1x1 128->200 @20x16 (ragged pixels and channels)", 100, 128, 0, 20, 16, 200, 1, (0, 0, 0, 0), 2, False, False),
     ("c16 head 1x1 384->96 @64", 4, 384, 0, 64, 64, 96, 1, (0, 0, 0, 0), 1, True, False),
     ("c16 ragged 40->70 @24x48 pad(1,1,2,0)", 6, 40, 0, 24, 48, 70, 3, (1, 1, 2, 0), 2, False, False),
     ("c16 filled-size 48->48 @96x128", 1, 48, 0, 96, 128, 48, 3, (2, 0, 1, 1), 1, True, False),
