@@ -282,6 +282,7 @@ struct Tile16Args {
     const void *w16;     // [nblk][nchunks][G4][NT16][8]
     int G4, nchunks, ngFull, ngLast, c8Last;
     int PX, PXP, inRows, inCols;   // halo pixels of a tile (all its images), padded to 16; halo rows / cols per image
+    int ntiles;                    // imgGroups * tilesX * tilesY (workgroups are persistent over them)
     int diag;
 };
 
@@ -305,44 +306,57 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
     const int l15 = lane & 15, lq = lane >> 4;
     const int lgT = a.lgTC + a.lgTR;
     const int NI = 512 >> lgT;
-    int bid = blockIdx.x;
-    {   // contiguous runs of tiles per XCD
-        const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
-        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    }
-    const int tx = bid % a.tilesX;
-    bid /= a.tilesX;
-    const int ty = bid % a.tilesY;
-    const int ig = bid / a.tilesY;
     const int nb = blockIdx.y;
-    const int oy0 = ty << a.lgTR, ox0 = tx << a.lgTC, n0 = ig * NI;
-    const int iy0 = oy0 - a.padT, ix0 = ox0 - a.padL;
     const int Cin = a.C1 + a.C2, HW = a.Hin * a.Win;
     const int TCm = (1 << a.lgTC) - 1, TRm = (1 << a.lgTR) - 1;
+    const int ntiles = k.ntiles;
 
-    // ---- this thread's share of the tile fetch: up to 3 (channel group, halo pixel) items ----------------------
-    // item i = tid + 512 r: channel group cg = i / P64 (wave-uniform: P64 is a multiple of 64), halo pixel i % P64
+    // ---- this thread's share of a tile fetch: up to 3 (channel group, halo pixel) items ------------------------------
+    // item i = tid + 512 r: channel group cg = i / P64 (wave-uniform: P64 is a multiple of 64), halo pixel i % P64.
+    // Fixed per thread: the LDS slot and the halo position (image, row, column inside the tile); per tile: the offsets.
     const int P64 = (k.PX + 63) & ~63;
     const int imgPix = k.inRows * k.inCols;
-    int voff1[3], voff2[3], wofs[3];
+    int wofs[3], hil[3], hrr[3], hcc[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int i = tid + r * kTileThreads;
         const int cg = i / P64, px = i - cg * P64;
-        voff1[r] = voff2[r] = (int)0x80000000;     // beyond the buffer range: the load returns 0
         wofs[r] = -1;
+        hil[r] = hrr[r] = hcc[r] = 0;
         if (cg < 2 && px < k.PX) {
-            const int il = px / imgPix, rem = px - il * imgPix;
-            const int rr = rem / k.inCols, cc = rem - rr * k.inCols;
-            const int n = n0 + il, iy = iy0 + rr, ix = ix0 + cc;
+            hil[r] = px / imgPix;
+            const int rem = px - hil[r] * imgPix;
+            hrr[r] = rem / k.inCols;
+            hcc[r] = rem - hrr[r] * k.inCols;
             wofs[r] = (cg * k.PXP + px) * 16;
-            if (n < a.N && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win) {
-                const int pix = iy * a.Win + ix;
-                voff1[r] = (il * a.C1 * HW + pix) * 4;
-                voff2[r] = (il * a.C2 * HW + pix) * 4;
-            }
         }
     }
+    int voff1[3], voff2[3];
+    int n0 = 0, oy0 = 0, ox0 = 0;     // tile whose input is being fetched
+    auto setup = [&](int t) {
+        // contiguous runs of tiles per XCD (blocks b and b + 8 share an XCD and its L2; vertically adjacent tiles
+        // share halo rows), then tile -> (image group, tile row, tile column)
+        int bid = t;
+        {
+            const int q = ntiles >> 3, rr = ntiles & 7, xcd = bid & 7;
+            bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+        }
+        bid = __builtin_amdgcn_readfirstlane(bid);
+        const int tx = bid % a.tilesX;
+        bid /= a.tilesX;
+        const int ty = bid % a.tilesY;
+        const int ig = bid / a.tilesY;
+        oy0 = ty << a.lgTR; ox0 = tx << a.lgTC; n0 = ig * NI;
+        const int iy0 = oy0 - a.padT, ix0 = ox0 - a.padL;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int n = n0 + hil[r], iy = iy0 + hrr[r], ix = ix0 + hcc[r];
+            const bool ok = wofs[r] >= 0 && n < a.N && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            const int pix = iy * a.Win + ix;
+            voff1[r] = ok ? (hil[r] * a.C1 * HW + pix) * 4 : (int)0x80000000;   // beyond the buffer range: the load returns 0
+            voff2[r] = ok ? (hil[r] * a.C2 * HW + pix) * 4 : (int)0x80000000;
+        }
+    };
     float f[3][8];
     auto fetch = [&](int c0) {      // channels c0 .. c0+15 of the concatenated input -> registers
         // buffer bases at the chunk's first channel of each source: the per-channel scalar offset stays small
@@ -409,102 +423,107 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
         const int il = p >> lgT, rr = (p >> a.lgTC) & TRm, c = p & TCm;
         abase[mt] = ((il * k.inRows + rr) * k.inCols + c) * 16;
     }
-    f32x4 acc[MT][NT];
+    const int baddr0 = stage0 + inBytes + (lq * NT16 + l15) * 16;
+    constexpr int bstep = 4 * NT16 * 16;
+    const long planeO = (long)a.Hout * a.Wout, planeY = a.up2 ? planeO * 4 : planeO;
+    const long W2 = 2L * a.Wout;
+    // per-channel epilogue constants, loaded ONCE up front: a load inside the store loop would make every channel
+    // tile wait (vmcnt counts in order) until all stores issued before it have completed
+    float esc[NT], esh[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = nb * NT16 + nt * 16 + l15;
+        esc[nt] = 1.f;
+        esh[nt] = 0.f;
+        if (co < a.Cout) {
+            if (a.scale) {
+                esc[nt] = a.scale[co];
+                esh[nt] = a.shift[co];
+            } else if (a.bias) {
+                esh[nt] = a.bias[co];
+            }
+        }
+    }
 
+    // The workgroup is persistent: tiles blockIdx.x, + gridDim.x, ...  After a tile's last chunk the NEXT tile's first
+    // fetch and weight chunk are issued before this tile's stores, so the stores of one tile and the loads of the next
+    // share the memory system instead of taking turns.
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    setup(tile);
     fetch(0);
     weights(0, 0);
     convert_store(0);
-    const int baddr0 = stage0 + inBytes + (lq * NT16 + l15) * 16;
-    constexpr int bstep = 4 * NT16 * 16;
-    for (int ci = 0; ci < k.nchunks; ++ci) {
-        __syncthreads();     // stage ci&1 complete (every wave's ds_writes and DMA); the other stage is free again
-        const bool more = ci + 1 < k.nchunks;
-        if (more) {
-            fetch((ci + 1) * kTileCK);          // in flight while this chunk is multiplied
-            weights(ci + 1, (ci + 1) & 1);
-        }
-        if (!(k.diag & 4)) {
-            const bool lastc = !more;
-            const int nks = ((lastc ? k.ngLast : k.ngFull) + 3) >> 2;
-            const int sb = (ci & 1) * stageBytes;
-            const int gaddr = lds_addr(gtab + (lastc ? k.G4 : 0) + lq);
-            const int ain = stage0 + sb, bb0 = baddr0 + sb;
-            for (int ks = 0; ks < nks; ++ks) {
-                const int goff = lds_i(gaddr)[ks * 4] + ain;
-                V8 av[MT], bv[NT];
+    for (;;) {
+        f32x4 acc[MT][NT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(abase[mt] + goff);
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(bb0 + ks * bstep + nt * 256);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Op16<T>::mma(av[mt], bv[nt], acc[mt][nt]);
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ci = 0; ci < k.nchunks; ++ci) {
+            __syncthreads();     // stage ci&1 complete (every wave's ds_writes and DMA); the other stage is free again
+            const bool more = ci + 1 < k.nchunks;
+            if (more) {
+                fetch((ci + 1) * kTileCK);          // in flight while this chunk is multiplied
+                weights(ci + 1, (ci + 1) & 1);
             }
-        }
-        if (more) convert_store((ci + 1) & 1);   // waits for the fetch (vmcnt), converts, writes the other stage
-    }
-    if (k.diag & 8) return;
-    // ---- epilogue: bias / affine / activation in registers, then through LDS so that global stores are whole rows ----
-    // The accumulator layout puts the 16 output CHANNELS of a tile on 16 lanes: stored directly, a wave instruction
-    // writes 64 B to each of 16 channel planes and the kernel is bound by store issue (measured: 88 of 187 us on
-    // 96->96 at 128x64^2).  Each wave transposes its own 64 pixels x 48 channels per pass in a private LDS region
-    // ([channel][64 pixels + 4 pad] floats, no workgroup barrier: a wave only reads what it wrote) and then stores
-    // 4 channel rows x 256 B per instruction.  Falls back to the shared epilogue for residual / unaligned outputs.
-    if (a.res || !a.vec4 || (a.Wout & 3)) {
-#include "conv_epilogue.inc"
-        return;
-    }
-    __syncthreads();                       // every wave is done with the stages: LDS is free
-    {
-        constexpr int ROWF = 68;           // floats per channel row in LDS (64 pixels + 4: conflict-free b128 accesses)
-        const int region = lds_addr(smem) + 256 + wave * (48 * ROWF * 4);
-        typedef __attribute__((address_space(3))) f32x4 *lds_f4w;
-        typedef const __attribute__((address_space(3))) f32x4 *lds_f4r;
-        // pixel part of the store address of this lane's readback chunk (4 consecutive pixels of the wave's 64)
-        const int chunk = lane & 15, rsub = lane >> 4;
-        const int p = wave * 64 + chunk * 4;
-        const int il = p >> lgT, pr = (p >> a.lgTC) & TRm, pc = p & TCm;
-        const int n = n0 + il, oy = oy0 + pr, ox = ox0 + pc;
-        const bool pok = n < a.N && oy < a.Hout && ox < a.Wout;
-        const long planeO = (long)a.Hout * a.Wout, planeY = a.up2 ? planeO * 4 : planeO;
-        const long W2 = 2L * a.Wout;
-        const long pixoff = (long)n * a.Cout * planeY + (a.up2 ? (long)(2 * oy) * W2 + 2 * ox : (long)oy * a.Wout + ox);
+            if (!(k.diag & 4)) {
+                const bool lastc = !more;
+                const int nks = ((lastc ? k.ngLast : k.ngFull) + 3) >> 2;
+                const int sb = (ci & 1) * stageBytes;
+                const int gaddr = lds_addr(gtab + (lastc ? k.G4 : 0) + lq);
+                const int ain = stage0 + sb, bb0 = baddr0 + sb;
+                for (int ks = 0; ks < nks; ++ks) {
+                    const int goff = lds_i(gaddr)[ks * 4] + ain;
+                    V8 av[MT], bv[NT];
 #pragma unroll
-        for (int half = 0; half < NT / 3; ++half) {
+                    for (int mt = 0; mt < MT; ++mt) av[mt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(abase[mt] + goff);
 #pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) {
-                const int nt = half * 3 + t3;
-                const int co = nb * NT16 + nt * 16 + l15;
-                float sc = 1.f, sh = 0.f;
-                if (co < a.Cout) {
-                    if (a.scale) {
-                        sc = a.scale[co];
-                        sh = a.shift[co];
-                    } else if (a.bias) {
-                        sh = a.bias[co];
-                    }
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(bb0 + ks * bstep + nt * 256);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Op16<T>::mma(av[mt], bv[nt], acc[mt][nt]);
                 }
+            }
+            if (more) convert_store((ci + 1) & 1);   // waits for the fetch (vmcnt), converts, writes the other stage
+        }
+        // ---- this tile's output coordinates, then the next tile's first loads, then the stores --------------------------
+        const int e_n0 = n0, e_oy0 = oy0, e_ox0 = ox0;
+        const int next = tile + (int)gridDim.x;
+        const bool more_tiles = next < ntiles;
+        __syncthreads();                                 // every wave has finished reading the stages
+        if (more_tiles) {
+            setup(next);
+            fetch(0);
+            weights(0, 0);
+        }
+        if (!(k.diag & 8)) {
+            // D layout: col(n) = lane & 15 -> output channel, row(m) = (lane >> 4) * 4 + reg -> 4 consecutive pixels
+            long poff[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int p = (wave * MT + mt) * 16 + lq * 4;
+                const int il = p >> lgT, r = (p >> a.lgTC) & TRm, cc = p & TCm;
+                const int n = e_n0 + il, oy = e_oy0 + r, ox = e_ox0 + cc;
+                const bool ok = n < a.N && oy < a.Hout && ox < a.Wout;
+                const long pix = a.up2 ? (long)(2 * oy) * W2 + 2 * ox : (long)oy * a.Wout + ox;
+                poff[mt] = ok ? (long)n * a.Cout * planeY + pix : -1;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = nb * NT16 + nt * 16 + l15;
+                if (co >= a.Cout) continue;
+                const float sc = esc[nt], sh = esh[nt];
+                float *yc = a.y + co * planeY;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    f32x4 v = acc[mt][nt];
+                    if (poff[mt] < 0) continue;
+                    const f32x4 c = acc[mt][nt];
+                    float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j] * sc + sh, a.act);
-                    *(lds_f4w)(__SIZE_TYPE__)(unsigned)(region + ((t3 * 16 + l15) * ROWF + mt * 16 + lq * 4) * 4) = v;
-                }
-            }
-            // rows 4i .. 4i+3 of the 48: lane -> (row 4i + rsub, 16-byte chunk)
-#pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                const int row = 4 * i + rsub;
-                const f32x4 v = *(lds_f4r)(__SIZE_TYPE__)(unsigned)(region + (row * ROWF + chunk * 4) * 4);
-                const int co = nb * NT16 + half * 48 + row;
-                if (pok && co < a.Cout) {
-                    float *q = a.y + pixoff + (long)co * planeY;
+                    for (int j = 0; j < 4; ++j) v[j] = apply_act(c[j] * sc + sh, a.act);
+                    float *q = yc + poff[mt];
                     if (a.up2) {
                         const float4 lo = make_float4(v[0], v[0], v[1], v[1]), hi = make_float4(v[2], v[2], v[3], v[3]);
                         *reinterpret_cast<float4 *>(q) = lo;
@@ -517,6 +536,9 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
                 }
             }
         }
+        if (!more_tiles) break;
+        convert_store(0);
+        tile = next;
     }
 }
 
@@ -623,17 +645,27 @@ __global__ __launch_bounds__(512) void conv16_head_kernel(const Head16Args a) {
         if (more) convert_store((c + 1) & 1);
     }
     // epilogue: D layout col(n) = lane & 15 -> output channel, row(m) = (lane >> 4) * 4 + reg -> 4 consecutive pixels
+    // (per-channel constants first, all of them: a load between stores would wait for every store before it)
+    float esc[6], esh[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+        const int co = cq * 96 + nt * 16 + l15;
+        esc[nt] = 1.f;
+        esh[nt] = 0.f;
+        if (co < a.Cout) {
+            if (a.scale) {
+                esc[nt] = a.scale[co];
+                esh[nt] = a.shift[co];
+            } else if (a.bias) {
+                esh[nt] = a.bias[co];
+            }
+        }
+    }
 #pragma unroll
     for (int nt = 0; nt < 6; ++nt) {
         const int co = cq * 96 + nt * 16 + l15;
         if (co >= a.Cout) continue;
-        float sc = 1.f, sh = 0.f;
-        if (a.scale) {
-            sc = a.scale[co];
-            sh = a.shift[co];
-        } else if (a.bias) {
-            sh = a.bias[co];
-        }
+        const float sc = esc[nt], sh = esh[nt];
         float *yc = a.y + ((long)n * a.Cout + co) * a.HW + p0 + pg * 64 + lq * 4;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -765,15 +797,18 @@ bool plan_tile(int Nimg, int Ck, int Nn, int Ho, int Wo, PlanT *p) {
     p->PXP = sprk::roundup(p->PX, 16);
     p->G4 = 20;                                   // 9 taps x 2 channel groups, padded to whole k-steps
     p->nchunks = cdiv(Ck, kTileCK);
-    p->ldsBytes = 256 + std::max(2 * ((size_t)2 * p->PXP * 16 + (size_t)p->G4 * p->NT * 16 * 16),
-                                 (size_t)8 * 48 * 68 * 4);      // two stages | the epilogue's 8 transpose regions
+    p->ldsBytes = 256 + 2 * ((size_t)2 * p->PXP * 16 + (size_t)p->G4 * p->NT * 16 * 16);
     p->wsBytes = (size_t)p->nblkN * p->nchunks * p->G4 * p->NT * 16 * 16;
     return true;
 }
 
 template <typename T>
 int launch_tile(const Tile16Args &k, const PlanT &p, hipStream_t s) {
-    dim3 grid(p.imgGroups * p.tilesX * p.tilesY, p.nblkN);
+    // persistent workgroups: one per CU (8 waves at 159-225 VGPRs fill it), shared among the output-channel blocks
+    const int ntiles = p.imgGroups * p.tilesX * p.tilesY;
+    static const int persist = getenv("SPRK_C16_PERSIST") ? atoi(getenv("SPRK_C16_PERSIST")) : 1;   // debug: 0 = one tile each
+    const int slots = std::max(1, 256 / p.nblkN);
+    dim3 grid(persist ? std::min(ntiles, slots) : ntiles, p.nblkN);
     auto go = [&](auto kernel) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)p.ldsBytes) != hipSuccess) {
@@ -879,6 +914,7 @@ static int run_tile(const Conv16Call &c, const PlanT &p, const float *x, const f
     k.c8Last = cdiv(ckeLast, 8);
     k.ngLast = 9 * k.c8Last;
     k.PX = p.PX; k.PXP = p.PXP; k.inRows = p.inRows; k.inCols = p.inCols;
+    k.ntiles = p.imgGroups * p.tilesX * p.tilesY;
     static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
     k.diag = diag;
     prof_begin(c.kclass, c.flops, s);
