@@ -108,6 +108,7 @@ def test_joint_train_step_matches_reference(denoiser, tag):
     close(o[P.DETECT_LOSS].reshape(()), g["DETECT_LOSS"], name="DETECT_LOSS")
     close(o[P.AUG_LOSS].reshape(()), g["AUG_LOSS"], rel=1e-3, name="AUG_LOSS")
     nograd = set(g["nograd"].tolist())
+    out_of_budget = []
     for name, p in denoiser.models.named_parameters():
         if name in nograd:
             assert p.grad is None, name
@@ -126,6 +127,17 @@ def test_joint_train_step_matches_reference(denoiser, tag):
             # same two flips.  Per-operator gradients are checked at 5e-5 in test_gpu_ops.py.
             assert err <= 3e-3 * absmax + 1e-4, "%s: probe err %.3e vs max|g| %.3e" % (name, err, absmax)
             assert abs(np.linalg.norm(a) / float(g[key + "/norm"]) - 1) < 2e-3 or absmax < 1e-3, name
+            # ... and the 3e-3 is for the sign-flip casualties only: over all tensors at most 0.5 % of the sampled
+            # gradient values may be beyond 1e-3 of their tensor's max|g| (counted below: 0.1 %)
+            errs = np.abs(a[g[key + "/idx"]] - g[key + "/val"])
+            loose = int((errs > 1e-3 * absmax + 1e-6).sum())
+            out_of_budget.append((name, loose, len(errs), float(errs.max() / (absmax + 1e-30))))
+    total_loose, total = sum(n for _, n, _, _ in out_of_budget), sum(m for _, _, m, _ in out_of_budget)
+    worst = sorted(out_of_budget, key=lambda t: -t[3])[:4]
+    print("gradient probes beyond 1e-3 of max|g|: %d of %d; worst tensors %s" % (
+        total_loose, total, [(n.split("denoiser_model.")[-1], "%.1e" % w) for n, _, _, w in worst]))
+    # measured: 2-4 of 14 470 (the two BatchNorm-before-BatchNorm parameters whose true gradient is zero)
+    assert total_loose <= total // 1000, "more than 0.1 %% of the gradient probes are beyond 1e-3 of max|g|"
     sd = denoiser.models["denoiser_model"].detector.state_dict()
     for k in g.files:
         if k.startswith("bn_after/"):
