@@ -66,6 +66,9 @@ typedef struct sprk_conv_geom {
 /* or-ed into dtype: take the 16-bit kernel for every layer it covers, also where the library's own choice would be
  * the fp32 Winograd kernel because it is faster there (wide 3x3 layers on planes >= 64x64); used by the parity tests */
 #define SPRK_DT_FORCE 0x100
+/* or-ed into dtype: run this call on the plain per-output-element kernels (no MFMA, no Winograd): the on-device
+ * cross-check the parity tests use.  Per call — the library keeps no mode switch. */
+#define SPRK_DT_NAIVE 0x200
 
 /* Optional fused epilogue of sprk_conv2d_fwd, applied in this order:
  *   v = acc (+ res[n,co,oy+res_off,ox+res_off])            res: [N,Cout,res_h,res_w]
@@ -93,8 +96,6 @@ long sprk_wino_launch_count(void);
 long sprk_conv16_launch_count(void);
 /* ... of those, the backward-weight launches */
 long sprk_wgrad16_launch_count(void);
-/* debug switch: 1 = route convolutions through the direct (non-MFMA) kernels */
-void sprk_set_naive(int on);
 
 /* ---- convolution: replaces F.conv2d/F.pad/crop of nn.Conv2d / ShiftConv2d ------------
  * reference: models/joint_network_v2.py:565-584 (ShiftConv2d), :33-153 (all U-Net convs),

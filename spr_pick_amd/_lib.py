@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(_HERE, "libsprk.so")
 
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2          # SPRK_DT_*: precision of the MFMA operands (include/sprk.h)
+DT_NAIVE = 0x200                           # SPRK_DT_NAIVE: plain per-output-element kernels for this call (cross-check)
 DT_FORCE = 0x100                           # SPRK_DT_FORCE: 16-bit kernel wherever it exists (tests), not only where faster
 DTYPES = {"f32": DT_F32, "fp32": DT_F32, "bf16": DT_BF16, "f16": DT_F16, "fp16": DT_F16,
           "bf16!": DT_BF16 | DT_FORCE, "f16!": DT_F16 | DT_FORCE}
@@ -37,7 +38,6 @@ _SIGS = {
     "sprk_wino_launch_count": (ctypes.c_long, []),
     "sprk_conv16_launch_count": (ctypes.c_long, []),
     "sprk_wgrad16_launch_count": (ctypes.c_long, []),
-    "sprk_set_naive": (None, [c_i]),
     "sprk_conv2d_fwd_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_fwd": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue), c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_data_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),

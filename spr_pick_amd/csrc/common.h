@@ -12,7 +12,6 @@ namespace sprk {
 
 void set_error(const char *fmt, ...);
 extern std::atomic<long> g_launches, g_wino_launches;
-extern int g_naive;
 
 // event bracketing of the MFMA convolution launches (sprk_prof_*)
 void prof_begin(int kclass, double flops, hipStream_t s);

@@ -15,7 +15,7 @@
 // held by one 32-lane ds_read group fall on disjoint banks (MI355X_MICROARCH.md §LDS).
 // The "direct" kernels at the end are the plain per-output-element statement of the same
 // maths: they serve strided backward-data (tiny detector layers) and as an on-device
-// cross-check (sprk_set_naive).
+// cross-check (SPRK_DT_NAIVE in sprk_conv_geom.dtype).
 #include "common.h"
 #include "conv16.h"
 #include "wgrad16.h"
@@ -27,6 +27,9 @@
 
 
 namespace {
+
+// per-call switch: SPRK_DT_NAIVE in sprk_conv_geom.dtype routes the call to the plain (non-MFMA) kernels
+inline bool naive_of(const sprk_conv_geom *g) { return (g->dtype & SPRK_DT_NAIVE) != 0; }
 
 constexpr int kClass16 = 5;   // profiling class of the 16-bit-operand forward / backward-data kernel (conv16.hip)
 constexpr int kClass16W = 6;  // ... of the 16-bit-operand backward-weight kernel (wgrad16.hip)
@@ -1406,13 +1409,13 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
     sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE, 0};
     if (!ep) ep = &e0;
     SPRK_REQUIRE(!ep->scale || ep->shift, "conv2d_fwd: scale without shift");
-    if (sprk::g_naive) {
+    if (naive_of(g)) {
         DirectArgs a{x, x2, w, nullptr, y, *g, *ep};
         const long total = (long)g->N * g->Cout * g->Hout * g->Wout;
         hipLaunchKernelGGL(conv_fwd_direct_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, s, a);
         return sprk::check_launch("conv_fwd_direct");
     }
-    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !sprk::g_naive) {
+    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !naive_of(g)) {
         const sprk::Conv16Call c16 = call16_fwd(g, ep);
         if (sprk::conv16_eligible(c16)) return sprk::conv16_run(c16, x, x2, w, y, ws, ws_bytes, s);
     }
@@ -1476,7 +1479,7 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
     SPRK_REQUIRE(gy && w && gin, "conv2d_bwd_data: null tensor");
     hipStream_t s = (hipStream_t)stream;
     const int Cin = g->C1 + g->C2;
-    if (sprk::g_naive || g->stride != 1) {
+    if (naive_of(g) || g->stride != 1) {
         sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE, 0};
         DirectArgs a{nullptr, nullptr, w, gy, gin, *g, e0};
         const long total = (long)g->N * Cin * g->Hin * g->Win;
@@ -1484,7 +1487,7 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
         return sprk::check_launch("conv_bwd_data_direct");
     }
     // gin = correlation of gy with the flipped, channel-transposed kernel
-    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !sprk::g_naive) {
+    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !naive_of(g)) {
         const sprk::Conv16Call c16 = call16_bwd(g);
         if (sprk::conv16_eligible(c16)) return sprk::conv16_run(c16, gy, nullptr, w, gin, ws, ws_bytes, s);
     }
@@ -1546,11 +1549,11 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     SPRK_REQUIRE(g->C2 == 0 || x2, "conv2d_bwd_weight: C2 > 0 but x2 is null");
     hipStream_t s = (hipStream_t)stream;
     const int Cin = g->C1 + g->C2;
-    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !sprk::g_naive) {
+    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !naive_of(g)) {
         const sprk::Wgrad16Call c16 = call16_wgrad(g);
         if (sprk::wgrad16_eligible(c16)) return sprk::wgrad16_run(c16, x, x2, gy, gw, ws, ws_bytes, s);
     }
-    if (!sprk::g_naive && sprk::wino_wgrad_eligible(wino_geom_fwd(g, nullptr))) {
+    if (!naive_of(g) && sprk::wino_wgrad_eligible(wino_geom_fwd(g, nullptr))) {
         const size_t need = sprk::wino_wgrad_ws_bytes(g->C1, g->C2, g->Cout);
         if (ws_bytes < need || !ws) {
             sprk::set_error("conv2d_bwd_weight: workspace %zu < %zu", ws_bytes, need);
@@ -1562,7 +1565,7 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     }
     WgPlan p;
     const bool ok = plan_wgrad(g, &p);
-    if (sprk::g_naive || !ok) {
+    if (naive_of(g) || !ok) {
         sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE, 0};
         DirectArgs a{x, x2, nullptr, gy, gw, *g, e0};
         hipLaunchKernelGGL(conv_bwd_weight_direct_kernel, dim3(g->Cout * Cin), dim3(256), 0, s, a);

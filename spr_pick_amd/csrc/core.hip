@@ -11,7 +11,6 @@ namespace sprk {
 
 static thread_local char t_error[512] = "";
 std::atomic<long> g_launches{0}, g_wino_launches{0};
-int g_naive = 0;
 
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -65,7 +64,6 @@ const char *sprk_last_error(void) { return sprk::t_error; }
 int sprk_version(void) { return 100; }
 long sprk_launch_count(void) { return sprk::g_launches.load(); }
 long sprk_wino_launch_count(void) { return sprk::g_wino_launches.load(); }
-void sprk_set_naive(int on) { sprk::g_naive = on ? 1 : 0; }
 long sprk_conv16_launch_count(void) { return sprk::conv16_launches() + sprk::wgrad16_launches(); }
 long sprk_wgrad16_launch_count(void) { return sprk::wgrad16_launches(); }
 

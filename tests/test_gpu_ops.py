@@ -93,10 +93,12 @@ def test_conv2d_fwd_bwd(case, naive):
     b = torch.randn(Cout, generator=g) * 0.1 if has_b else None
     d = dev()
     L = _lib.lib()
-    L.sprk_set_naive(naive)
     try:
         dl = [t.to(d).requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
-        y = ops.conv2d(dl[0], dl[2], dl[3], x2=dl[1], up1=bool(up1), stride=stride, dil=dil, pad=pad, act=act)
+        # "direct": SPRK_DT_NAIVE in the geometry's dtype routes this call (forward and both backward kernels) to the
+        # plain per-output-element kernels — a per-call flag, the library keeps no mode
+        y = ops.conv2d(dl[0], dl[2], dl[3], x2=dl[1], up1=bool(up1), stride=stride, dil=dil, pad=pad, act=act,
+                       dtype=_lib.DT_NAIVE if naive else 0)
         # fp64 CPU reference.  The backward of (Leaky)ReLU depends on the SIGN of the pre-activation;
         # an fp32 result within rounding of zero may legitimately land on the other side than the
         # fp64 one, so the reference backward uses the sign pattern of the GPU output.
@@ -114,7 +116,7 @@ def test_conv2d_fwd_bwd(case, naive):
         y.backward(gy.to(d))
         torch.cuda.synchronize()
     finally:
-        L.sprk_set_naive(0)
+        pass
     # gradients sum over up to N*H*W terms: budget relative to the gradient's own scale
     close(dl[0].grad, leaves[0].grad, rel=5e-5, name=name + " gx")
     if x2 is not None:
@@ -181,7 +183,7 @@ def test_conv2d_winograd(case):
 
 def test_conv2d_winograd_affine_epilogue_and_switch():
     """Inference epilogue relu(conv * scale + shift) on the Winograd kernel, and SPRK_WINO-independent
-    agreement with the direct MFMA kernel on the same input (sprk_set_naive routes around both)."""
+    agreement with the plain direct kernel on the same input (SPRK_DT_NAIVE routes around both)."""
     from spr_pick_amd import _lib, ops
     g = torch.Generator().manual_seed(11)
     x = torch.randn(4, 96, 96, 128, generator=g)
@@ -197,11 +199,8 @@ def test_conv2d_winograd_affine_epilogue_and_switch():
     y = ops.conv2d_forward(xd, None, wd, geom, act=ops.ACT_RELU, scale=scale.to(d), shift=shift.to(d))
     assert L.sprk_wino_launch_count() == before + 1
     close(y, want, name="wino affine epilogue")
-    L.sprk_set_naive(1)
-    try:
-        y2 = ops.conv2d_forward(xd, None, wd, geom, act=ops.ACT_RELU, scale=scale.to(d), shift=shift.to(d))
-    finally:
-        L.sprk_set_naive(0)
+    geom_direct = ops.make_geom(xd, None, wd, False, 1, 1, (2, 0, 1, 1), dtype=_lib.DT_NAIVE)
+    y2 = ops.conv2d_forward(xd, None, wd, geom_direct, act=ops.ACT_RELU, scale=scale.to(d), shift=shift.to(d))
     assert L.sprk_wino_launch_count() == before + 1
     close(y, y2, name="wino vs direct kernel")
 
