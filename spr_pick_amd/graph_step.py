@@ -211,7 +211,12 @@ class GraphedTrainStep:
         self.grads.begin_step()
         torch.cuda.synchronize(self.dev)
         n0 = L.sprk_launch_count()
-        with torch.cuda.graph(g, pool=self._pool, stream=self._side):
+        # With a process group alive, RCCL's watchdog thread polls its events with hipEventQuery at any time; under
+        # the default "global" capture mode a query from ANOTHER thread invalidates the capture.  "thread_local"
+        # restricts the check to the capturing thread (the kernels the autograd thread enqueues on the capturing
+        # stream are captured either way: capture is a property of the stream).
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        with torch.cuda.graph(g, pool=self._pool, stream=self._side, capture_error_mode=mode):
             with self.grads:
                 o = self._pass(flip_p)
         self.kernels_per_step = L.sprk_launch_count() - n0
