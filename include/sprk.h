@@ -121,6 +121,32 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
 size_t sprk_act_bwd_ws_bytes(int N, int C, int HW);
 int sprk_act_bwd(const float *gy, const float *y, float *gpre, float *gbias, int act,
                  int N, int C, int H, int W, int up2, void *ws, size_t ws_bytes, void *stream);
+/* ---- deferred second-stage reductions ------------------------------------------------------
+ * Backward-weight and the bias gradient are two-stage sums: the main kernel leaves per-workgroup partial sums in
+ * ws and a small second kernel adds them in a fixed order.  A training step runs ~80 of those second kernels
+ * (5 us of dispatch each).  The *_partial entry points run only the main kernel and describe the pending sum in
+ * *item; sprk_reduce_items then finishes any number of them in one launch per 48 items.  Between the two calls the
+ * item's ws must stay untouched (give every call its own ws) and dst is undefined.  item->kind == SPRK_RED_NONE:
+ * the call already produced its final result (kernels without a partial stage).  The plain entry points above are
+ * the *_partial call followed by sprk_reduce_items on its one item: results are bit-identical either way. */
+#define SPRK_RED_NONE 0
+#define SPRK_RED_ROWS 1   /* dst[i] = sum_p src[p * n + i],                        i < n          */
+#define SPRK_RED_COLS 2   /* dst[i] = sum_p src[i * parts + p],                    i < n          */
+#define SPRK_RED_WGRAD 3  /* dst[co * K + k] = sum_p src[(p * K + k) * CoutP + co], co < Cout, k < K */
+typedef struct sprk_reduce_item {
+    const float *src;
+    float *dst;
+    int kind, parts, n, K, Cout, CoutP;
+} sprk_reduce_item;
+int sprk_conv2d_bwd_weight_partial(const float *x, const float *x2, const float *gy, float *gw,
+                                   const sprk_conv_geom *g, void *ws, size_t ws_bytes,
+                                   sprk_reduce_item *item, void *stream);
+int sprk_act_bwd_partial(const float *gy, const float *y, float *gpre, float *gbias, int act,
+                         int N, int C, int H, int W, int up2, void *ws, size_t ws_bytes,
+                         sprk_reduce_item *item, void *stream);
+/* every sum: four interleaved chains over p (p mod 4), combined as (s0 + s1) + (s2 + s3) */
+int sprk_reduce_items(const sprk_reduce_item *items, int n, void *stream);
+
 /* split the gradient of a fused (upsample2(a) ++ b) conv input: ga[N,C1,H/2,W/2] = 2x2 sums
  * of gin[:, :C1], gb[N,C2,H,W] = gin[:, C1:].  (autograd of nn.Upsample + torch.cat) */
 int sprk_concat_up_bwd(const float *gin, float *ga, float *gb, int N, int C1, int C2, int H, int W,
@@ -143,12 +169,16 @@ int sprk_unrot4_shift_concat_bwd(const float *gf, float *gd, int B, int C, int P
 /* ---- BatchNorm2d (+ optional ReLU), detector: joint_network_v2.py:547,558;
  * feature_extractor.py:287-288,320-324,338-346,412-414.
  * train: batch statistics (biased var for normalisation, unbiased for the running update,
- * momentum 0.1) saved to save_mean/save_invstd [C]; eval: running statistics.
+ * momentum 0.1) saved to save_mean/save_invstd [groups][C]; eval: running statistics.
+ * groups: the batch is `groups` independent passes of N / groups images stacked along N (the reference calls the
+ * detector once per pass: patches, then their flipped copies): each group is normalised with its own batch
+ * statistics, the running averages are updated group after group and the parameter gradients are summed in
+ * group order, as if the module had been called once per pass.  groups = 1: plain BatchNorm2d.
  * ws (sprk_bn_ws_bytes): per-slice fp64 partial sums of the two-kernel reduction. */
-size_t sprk_bn_ws_bytes(int N, int C, int HW);
+size_t sprk_bn_ws_bytes(int N, int C, int HW, int groups);
 int sprk_bn_train_fwd(const float *x, float *y, const float *gamma, const float *beta,
                       float *running_mean, float *running_var, float *save_mean, float *save_invstd,
-                      int N, int C, int HW, float momentum, float eps, int relu,
+                      int N, int C, int HW, int groups, float momentum, float eps, int relu,
                       void *ws, size_t ws_bytes, void *stream);
 int sprk_bn_eval_fwd(const float *x, float *y, const float *gamma, const float *beta,
                      const float *running_mean, const float *running_var,
@@ -157,7 +187,7 @@ int sprk_bn_eval_fwd(const float *x, float *y, const float *gamma, const float *
 int sprk_bn_train_bwd(const float *gy, const float *x, const float *y, const float *gamma,
                       const float *save_mean, const float *save_invstd,
                       float *gx, float *ggamma, float *gbeta,
-                      int N, int C, int HW, int relu, void *ws, size_t ws_bytes, void *stream);
+                      int N, int C, int HW, int groups, int relu, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- per-pixel maths of the pipeline ---------------------------------------------------
  * reparameterize: z = mu + eps * A^2 on out_stats [B,2,H,W] (joint_network_v2.py:469-475) */

@@ -31,6 +31,12 @@ class ConvEpilogue(ctypes.Structure):
                 ("act", ctypes.c_int32), ("up2", ctypes.c_int32)]
 
 
+class ReduceItem(ctypes.Structure):
+    """sprk_reduce_item: a pending second-stage sum (include/sprk.h)."""
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("kind", ctypes.c_int32), ("parts", ctypes.c_int32), ("n", ctypes.c_int32),
+                ("K", ctypes.c_int32), ("Cout", ctypes.c_int32), ("CoutP", ctypes.c_int32)]
+
+
 _SIGS = {
     "sprk_last_error": (ctypes.c_char_p, []),
     "sprk_version": (c_i, []),
@@ -44,6 +50,9 @@ _SIGS = {
     "sprk_conv2d_bwd_data": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_weight_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_bwd_weight": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
+    "sprk_conv2d_bwd_weight_partial": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, ctypes.POINTER(ReduceItem), c_vp]),
+    "sprk_act_bwd_partial": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, ctypes.POINTER(ReduceItem), c_vp]),
+    "sprk_reduce_items": (c_i, [ctypes.POINTER(ReduceItem), c_i, c_vp]),
     "sprk_act_bwd_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "sprk_act_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "sprk_concat_up_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
@@ -53,10 +62,10 @@ _SIGS = {
     "sprk_rot4_stack_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
     "sprk_unrot4_shift_concat_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
     "sprk_unrot4_shift_concat_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
-    "sprk_bn_ws_bytes": (c_sz, [c_i, c_i, c_i]),
-    "sprk_bn_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_i, c_vp, c_sz, c_vp]),
+    "sprk_bn_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "sprk_bn_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_i, c_vp, c_sz, c_vp]),
     "sprk_bn_eval_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_vp]),
-    "sprk_bn_train_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "sprk_bn_train_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "sprk_reparam_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_vp]),
     "sprk_reparam_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_vp]),
     "sprk_sigmoid_clamp_fwd": (c_i, [c_f, c_f, ctypes.c_long, c_vp]),

@@ -27,6 +27,16 @@ inline int check_launch(const char *what) {
     return SPRK_OK;
 }
 
+// second-stage sums (sprk_reduce_items); item == nullptr in the callers below means "finish now"
+int reduce_items(const sprk_reduce_item *items, int n, hipStream_t s);
+inline int finish_or_defer(const sprk_reduce_item &it, sprk_reduce_item *out, hipStream_t s) {
+    if (out) {
+        *out = it;
+        return SPRK_OK;
+    }
+    return it.kind == SPRK_RED_NONE ? (int)SPRK_OK : reduce_items(&it, 1, s);
+}
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 inline int roundup(int a, int b) { return (a + b - 1) / b * b; }
 inline int pow2_ceil(int v) {

@@ -720,38 +720,6 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
     }
 }
 
-// out[co][c][tap] = sum_g partial[g][(c*KHW+tap)][co]
-// 64 consecutive slab elements per workgroup x 4 group lanes; every lane sums its quarter of the
-// groups with independent loads in flight, the four partial sums are added in a fixed order.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial,
-                                                              float *__restrict__ out, int K, int Cout, int CoutP,
-                                                              int groups) {
-    __shared__ float red[4][64];
-    const long slab = (long)K * CoutP;
-    const int gl = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long e = (long)blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (e < slab) {
-        const float *p = partial + e;
-        int g = gl;
-#pragma unroll 1
-        for (; g + 28 < groups; g += 32) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(long)(g + 4 * u) * slab];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; g < groups; g += 4) s += p[(long)g * slab];
-    }
-    red[gl][lane] = s;
-    __syncthreads();
-    if (gl == 0 && e < slab) {
-        const int co = (int)(e % CoutP);
-        const int k = (int)(e / CoutP);
-        if (co < Cout) out[(long)co * K + k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // direct kernels (plain statement of the maths)
@@ -946,14 +914,6 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const floa
         }
         if (threadIdx.x == 0) partial[c * nsplit + s] = red[0];
     }
-}
-
-__global__ void bias_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gb, int C, int nsplit) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int i = 0; i < nsplit; ++i) s += partial[c * nsplit + i];
-    gb[c] = s;
 }
 
 __global__ void concat_up_bwd_kernel(const float *__restrict__ gin, float *__restrict__ ga, float *__restrict__ gb,
@@ -1544,6 +1504,13 @@ size_t sprk_conv2d_bwd_weight_ws_bytes(const sprk_conv_geom *g) {
 
 int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, float *gw, const sprk_conv_geom *g,
                            void *ws, size_t ws_bytes, void *stream) {
+    return sprk_conv2d_bwd_weight_partial(x, x2, gy, gw, g, ws, ws_bytes, nullptr, stream);
+}
+
+// item == nullptr: finish the sum over the partial buffers now; otherwise describe it in *item (sprk.h)
+int sprk_conv2d_bwd_weight_partial(const float *x, const float *x2, const float *gy, float *gw, const sprk_conv_geom *g,
+                                   void *ws, size_t ws_bytes, sprk_reduce_item *item, void *stream) {
+    if (item) *item = sprk_reduce_item{nullptr, nullptr, SPRK_RED_NONE, 0, 0, 0, 0, 0};
     if (int rc = check_geom(g)) return rc;
     SPRK_REQUIRE(x && gy && gw, "conv2d_bwd_weight: null tensor");
     SPRK_REQUIRE(g->C2 == 0 || x2, "conv2d_bwd_weight: C2 > 0 but x2 is null");
@@ -1551,7 +1518,7 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     const int Cin = g->C1 + g->C2;
     if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !naive_of(g)) {
         const sprk::Wgrad16Call c16 = call16_wgrad(g);
-        if (sprk::wgrad16_eligible(c16)) return sprk::wgrad16_run(c16, x, x2, gy, gw, ws, ws_bytes, s);
+        if (sprk::wgrad16_eligible(c16)) return sprk::wgrad16_run(c16, x, x2, gy, gw, ws, ws_bytes, item, s);
     }
     if (!naive_of(g) && sprk::wino_wgrad_eligible(wino_geom_fwd(g, nullptr))) {
         const size_t need = sprk::wino_wgrad_ws_bytes(g->C1, g->C2, g->Cout);
@@ -1628,9 +1595,8 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
     sprk::prof_end(1, s);
     if (int rc2 = sprk::check_launch("conv_wgrad_mfma")) return rc2;
     const int K = Cin * g->KH * g->KW;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(sprk::cdiv((long)K * p.CoutP, 64)), dim3(256), 0, s,
-                       (const float *)(wsf + kZeroFloats), gw, K, g->Cout, p.CoutP, p.groups);
-    return sprk::check_launch("reduce_partials");
+    const sprk_reduce_item it{wsf + kZeroFloats, gw, SPRK_RED_WGRAD, p.groups, 0, K, g->Cout, p.CoutP};
+    return sprk::finish_or_defer(it, item, s);
 }
 
 static int act_nsplit(int N, int C) {
@@ -1646,6 +1612,12 @@ size_t sprk_act_bwd_ws_bytes(int N, int C, int HW) {
 
 int sprk_act_bwd(const float *g, const float *y, float *gpre, float *gbias, int act, int N, int C, int H, int W,
                  int up2, void *ws, size_t ws_bytes, void *stream) {
+    return sprk_act_bwd_partial(g, y, gpre, gbias, act, N, C, H, W, up2, ws, ws_bytes, nullptr, stream);
+}
+
+int sprk_act_bwd_partial(const float *g, const float *y, float *gpre, float *gbias, int act, int N, int C, int H, int W,
+                         int up2, void *ws, size_t ws_bytes, sprk_reduce_item *item, void *stream) {
+    if (item) *item = sprk_reduce_item{nullptr, nullptr, SPRK_RED_NONE, 0, 0, 0, 0, 0};
     SPRK_REQUIRE(g && N > 0 && C > 0 && H > 0 && W > 0, "act_bwd: bad arguments");
     SPRK_REQUIRE(act == SPRK_ACT_NONE || (y && gpre), "act_bwd: activation needs the saved output and gpre");
     SPRK_REQUIRE(!up2 || (gpre && gpre != g), "act_bwd: up2 needs a separate low-resolution gpre");
@@ -1660,8 +1632,8 @@ int sprk_act_bwd(const float *g, const float *y, float *gpre, float *gbias, int 
                        H * W, W, up2, ns);
     if (int rc = sprk::check_launch("act_bwd")) return rc;
     if (gbias) {
-        hipLaunchKernelGGL(bias_reduce_kernel, dim3(sprk::cdiv(C, 64)), dim3(64), 0, s, (const float *)ws, gbias, C, ns);
-        return sprk::check_launch("bias_reduce");
+        const sprk_reduce_item it{(const float *)ws, gbias, SPRK_RED_COLS, ns, C, 0, 0, 0};
+        return sprk::finish_or_defer(it, item, s);
     }
     return SPRK_OK;
 }

@@ -58,7 +58,100 @@ void prof_end(int kclass, hipStream_t s) {
 
 }  // namespace sprk
 
+namespace {
+
+constexpr int kRedMax = 48;
+struct RedTable {
+    sprk_reduce_item it[kRedMax];
+    int start[kRedMax + 1];   // first workgroup of item i
+    int n;
+};
+
+// sum over p < parts of p0[p * stride]: four interleaved chains (p mod 4), eight loads in flight
+__device__ __forceinline__ float sum4(const float *__restrict__ p0, long stride, int parts) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+#pragma unroll 1
+    for (; p + 7 < parts; p += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p0[(long)(p + u) * stride];
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+        s0 += v[4]; s1 += v[5]; s2 += v[6]; s3 += v[7];
+    }
+    for (; p + 3 < parts; p += 4) {
+        s0 += p0[(long)p * stride];
+        s1 += p0[(long)(p + 1) * stride];
+        s2 += p0[(long)(p + 2) * stride];
+        s3 += p0[(long)(p + 3) * stride];
+    }
+    if (p < parts) s0 += p0[(long)p * stride];
+    if (p + 1 < parts) s1 += p0[(long)(p + 1) * stride];
+    if (p + 2 < parts) s2 += p0[(long)(p + 2) * stride];
+    return (s0 + s1) + (s2 + s3);
+}
+
+// one thread per output element; workgroup -> item through the start table (kernel argument, scalar loads)
+__global__ __launch_bounds__(256) void reduce_items_kernel(const RedTable t) {
+    const int b = blockIdx.x;
+    int i = 0;
+    while (i + 1 < t.n && b >= t.start[i + 1]) ++i;
+    const sprk_reduce_item it = t.it[i];
+    const long e = (long)(b - t.start[i]) * 256 + threadIdx.x;
+    if (it.kind == SPRK_RED_ROWS) {
+        if (e < it.n) it.dst[e] = sum4(it.src + e, it.n, it.parts);
+    } else if (it.kind == SPRK_RED_COLS) {
+        if (e < it.n) it.dst[e] = sum4(it.src + e * it.parts, 1, it.parts);
+    } else {
+        const long slab = (long)it.K * it.CoutP;
+        if (e < slab) {
+            const int co = (int)(e % it.CoutP), k = (int)(e / it.CoutP);
+            if (co < it.Cout) it.dst[(long)co * it.K + k] = sum4(it.src + e, slab, it.parts);
+        }
+    }
+}
+
+}  // namespace
+
+namespace sprk {
+
+int reduce_items(const sprk_reduce_item *items, int n, hipStream_t s) {
+    int i = 0;
+    while (i < n) {
+        RedTable t{};
+        int blocks = 0;
+        while (i < n && t.n < kRedMax) {
+            const sprk_reduce_item &it = items[i++];
+            if (it.kind == SPRK_RED_NONE) continue;
+            if (!it.src || !it.dst || it.parts < 1 || it.n < 0 ||
+                (it.kind != SPRK_RED_ROWS && it.kind != SPRK_RED_COLS && it.kind != SPRK_RED_WGRAD) ||
+                (it.kind == SPRK_RED_WGRAD && (it.K < 1 || it.Cout < 1 || it.CoutP < it.Cout))) {
+                set_error("reduce_items: bad item %d (kind %d)", i - 1, it.kind);
+                return SPRK_EINVAL;
+            }
+            const long work = it.kind == SPRK_RED_WGRAD ? (long)it.K * it.CoutP : (long)it.n;
+            if (work == 0) continue;
+            t.it[t.n] = it;
+            t.start[t.n] = blocks;
+            blocks += cdiv(work, 256);
+            ++t.n;
+        }
+        if (t.n == 0) continue;
+        t.start[t.n] = blocks;
+        hipLaunchKernelGGL(reduce_items_kernel, dim3(blocks), dim3(256), 0, s, t);
+        if (int rc = check_launch("reduce_items")) return rc;
+    }
+    return SPRK_OK;
+}
+
+}  // namespace sprk
+
 extern "C" {
+
+int sprk_reduce_items(const sprk_reduce_item *items, int n, void *stream) {
+    SPRK_REQUIRE(n >= 0 && (n == 0 || items), "reduce_items: bad arguments");
+    return sprk::reduce_items(items, n, (hipStream_t)stream);
+}
 
 const char *sprk_last_error(void) { return sprk::t_error; }
 int sprk_version(void) { return 100; }

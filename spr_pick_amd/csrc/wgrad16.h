@@ -16,8 +16,9 @@ struct Wgrad16Call {
 
 bool wgrad16_eligible(const Wgrad16Call &c);
 size_t wgrad16_ws_bytes(const Wgrad16Call &c);
+// item: see sprk_conv2d_bwd_weight_partial (nullptr = add the workgroups' partial dW now)
 int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const float *gy, float *gw, void *ws,
-                size_t ws_bytes, hipStream_t s);
+                size_t ws_bytes, sprk_reduce_item *item, hipStream_t s);
 long wgrad16_launches();
 
 }  // namespace sprk

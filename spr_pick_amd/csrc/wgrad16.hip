@@ -14,7 +14,7 @@
 // accumulator tiles, dealt to the waves as 6 cout tiles x {every 8th (cin tile, tap) pair}: 96 accumulator registers,
 // per k-step 6 + 4 LDS reads for 24 MFMAs.  The next region is fetched HBM -> registers (32-byte runs per lane, zeros
 // outside the image through the buffer range check) under the current region's MFMAs, converted once and written
-// to the other LDS stage; one barrier per region.  Each workgroup leaves one partial dW; wgrad16_reduce_kernel adds
+// to the other LDS stage; one barrier per region.  Each workgroup leaves one partial dW; sprk_reduce_items adds
 // them in a fixed order (deterministic).  gy is read once per 48-channel input block, x once.
 #include "wgrad16.h"
 
@@ -59,6 +59,7 @@ struct Wg16Args {
     int seg, segLen;         // a strip (image, column block) is cut into `seg` vertical segments of segLen regions
     int nUnits;              // N * regX * seg
     int xcs;                 // bytes per input channel of the rolling x buffer (SLOTS rows x pitch x 2, bank spread)
+    int tail;                // 1: the last input channel (Cin = 48 k + 1) rides in block 0 as plane 48 (see below)
     int diag;
 };
 
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     constexpr int RW = 1 << LGRW, RH = kRegionPx / RW, SLOTS = 2 * RH + 2;
     constexpr int PITCH = RW + 16, XG4 = PITCH / 4;            // tile columns; column 8 = the region's first output column
     constexpr int GYN = MC * 16 * 32 / kWgThreads;             // gy items (cout, 4-pixel group) per thread: 6 or 3
-    constexpr int XROWIT = kCB * XG4;                          // x items (cin, 4-column group) per tile row
+    constexpr int XROWIT = (kCB + 1) * XG4;                    // x items (cin plane, 4-column group) per tile row
     constexpr int XN = (RH * XROWIT + kWgThreads - 1) / kWgThreads;   // per thread for a region's RH new rows: 4 or 5
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -81,7 +82,13 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     const int l15 = lane & 15, kq = lane >> 4;
     const int CinTot = a.C1 + a.C2, HW = a.H * a.W;
     const int cb0 = blockIdx.y * kCB;                          // first input channel of this block
-    const int cbn = min(kCB, CinTot - cb0);                    // channels present
+    const int cbn = min(kCB, CinTot - a.tail - cb0);           // channels present
+    // Cin = 48 k + 1 (a 96-channel skip concat + the 1-channel image): the odd channel does not get a block of its
+    // own.  Its plane is staged as plane 48 of block 0 and ONE more accumulator tile per cout tile covers all 9 taps
+    // at once: the B operand's n index is the TAP (lane l&15 reads the plane at its own (ky, kx) shift), in the
+    // 28th (cin tile, tap) slot, which wave 3 had free.
+    const bool tailHere = a.tail && blockIdx.y == 0;
+    const bool tailWave = tailHere && wave == 3;
     constexpr int gyBytes = MC * 16 * kGyStride;
     const int ldsGy = lds_addr(smem), ldsX = ldsGy + 2 * gyBytes;
 
@@ -101,15 +108,17 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     };
 
     // ---- per-thread item geometry (16-byte items: consecutive lanes on consecutive 16 bytes) -------------------------
-    int gyc[GYN], gyl[GYN];            // gy: byte offset inside an image relative to the region origin | LDS offset
-#pragma unroll
-    for (int i = 0; i < GYN; ++i) {
-        const int it = tid + i * kWgThreads;
-        const int co = it >> 5, p = (it & 31) * 4;
+    // gy item i of this thread = (cout (tid >> 5) + 16 i, 4-pixel group tid & 31): byte offset inside an image relative
+    // to the region origin and LDS offset are those of item 0 plus a constant per i (not held in registers)
+    const int gyco = tid >> 5, gyLim = (a.diag & 1) ? 0 : a.Cout;
+    int gyc0, gyl0;
+    {
+        const int p = (tid & 31) * 4;
         const int rr = p >> LGRW, cc = p & (RW - 1);
-        gyc[i] = (co < a.Cout && !(a.diag & 1)) ? ((co * a.H + rr) * a.W + cc) * 4 : (int)0x80000000;
-        gyl[i] = co * kGyStride + (it & 31) * 8;
+        gyc0 = ((gyco * a.H + rr) * a.W + cc) * 4;
+        gyl0 = gyco * kGyStride + (tid & 31) * 8;
     }
+    const int gycStep = 16 * HW * 4;
     // x items: byte offset inside the item's source relative to (tile row 0, column block), or the out-of-range marker |
     // packed: LDS offset (bits 0-19), tile row within the fetch (bits 20-23, 15 = no item), source 2 flag (bit 24)
     int xc[XN], xp[XN];
@@ -119,8 +128,9 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
             const int it = tid + i * kWgThreads;
             const int rloc = it / XROWIT, rem = it - rloc * XROWIT;
             const int cl = rem / XG4, g4 = rem - cl * XG4;
-            const int ch = cb0 + cl, ix = c0 - 8 + g4 * 4;
-            const bool ok = rloc < RH && cl < cbn && (unsigned)ix < (unsigned)a.W && !(a.diag & 1);
+            const int ch = cl < kCB ? cb0 + cl : CinTot - 1, ix = c0 - 8 + g4 * 4;
+            const bool ok = rloc < RH && (cl < cbn || (cl == kCB && tailHere)) && (unsigned)ix < (unsigned)a.W &&
+                            !(a.diag & 1);
             const bool s1 = ch < a.C1;
             const int cc = s1 ? ch : ch - a.C1;
             xc[i] = ok ? (cc * a.H * a.W + ix) * 4 : (int)0x80000000;
@@ -157,12 +167,14 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     };
     auto fetch_gy = [&](const rsrc_t rg, int org) {
 #pragma unroll
-        for (int i = 0; i < GYN; ++i) fg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, gyc[i], org, 0);
+        for (int i = 0; i < GYN; ++i)
+            fg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, gyco + 16 * i < gyLim ? gyc0 + i * gycStep : (int)0x80000000,
+                                                          org, 0);
     };
     auto store_gy = [&](int b) {
 #pragma unroll
         for (int i = 0; i < GYN; ++i)
-            *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(ldsGy + b * gyBytes + gyl[i]) = cvt4(fg[i]);
+            *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(ldsGy + b * gyBytes + gyl0 + i * 16 * kGyStride) = cvt4(fg[i]);
     };
 
     // ---- this wave's accumulator tiles: all MC cout tiles x pairs {wave, wave + 8, wave + 16, wave + 24} of the 27
@@ -183,6 +195,9 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
         blane[q] = ldsX + (it * 16 + l15) * a.xcs + (8 + kx - a.padL + kq * 8) * 2;
     }
     const int alane = ldsGy + l15 * kGyStride + kq * 16;
+    // tail tile: lane's tap = min(l & 15, 8) (columns 9..15 of D are not stored)
+    const int ttap = min(l15, 8), tky = ttap / 3, tkx = ttap - tky * 3;
+    const int tlane = ldsX + kCB * a.xcs + (8 + tkx - a.padL + kq * 8) * 2;
 
     for (int u = blockIdx.x; u < a.nUnits; u += gridDim.x) {
         const int sgi = u % a.seg;
@@ -226,7 +241,13 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
 #pragma unroll
                     for (int q = 0; q < NP; ++q) {
                         const int slot = (jrow + rr + bky[q]) % SLOTS;    // scalar
-                        bv[q] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(blane[q] + slot * (PITCH * 2) + cc2);
+                        int ba = blane[q] + slot * (PITCH * 2) + cc2;
+                        if (q == NP - 1 && tailWave) {                    // wave-uniform: per-lane tap row
+                            const int s0 = ((jrow + rr) % SLOTS) * (PITCH * 2), s1 = ((jrow + rr + 1) % SLOTS) * (PITCH * 2),
+                                      s2 = ((jrow + rr + 2) % SLOTS) * (PITCH * 2);
+                            ba = tlane + cc2 + (tky == 0 ? s0 : tky == 1 ? s1 : s2);
+                        }
+                        bv[q] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)ba;
                     }
 #pragma unroll
                     for (int m = 0; m < MC; ++m)
@@ -246,6 +267,18 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int pr = wave + 8 * q;
+        if (pr == 27 && tailHere) {                  // the tail channel's tile: column = tap
+            if (l15 < 9) {
+#pragma unroll
+                for (int m = 0; m < MC; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int co = m * 16 + kq * 4 + j;
+                        if (co < a.Cout) part[((long)co * CinTot + CinTot - 1) * 9 + l15] = acc[m][q][j];
+                    }
+            }
+            continue;
+        }
         if (pr >= 27) continue;
         const int it = pr / 9, tap = pr - it * 9;
         const int ci = cb0 + it * 16 + l15;
@@ -260,25 +293,8 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     }
 }
 
-// gw[i] = sum over parts of partial[p][i], parts added in index order by 4 lanes x independent chains (fixed order)
-__global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const float *__restrict__ partial, float *__restrict__ gw,
-                                                             long n, int parts) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int p = 0;
-    for (; p + 3 < parts; p += 4) {
-        s0 += partial[(long)p * n + i];
-        s1 += partial[(long)(p + 1) * n + i];
-        s2 += partial[(long)(p + 2) * n + i];
-        s3 += partial[(long)(p + 3) * n + i];
-    }
-    for (; p < parts; ++p) s0 += partial[(long)p * n + i];
-    gw[i] = (s0 + s1) + (s2 + s3);
-}
-
 struct PlanW {
-    int MC, lgRW, regX, regY, seg, segLen, nUnits, xcs, parts, nBlocks;
+    int MC, lgRW, regX, regY, seg, segLen, nUnits, xcs, parts, nBlocks, tail;
     size_t ldsBytes, wsBytes;
 };
 
@@ -316,7 +332,9 @@ static bool plan_wg16(const Wgrad16Call &c, PlanW *p) {
     const long regions = (long)c.N * p->regX * p->regY;
     if (regions < 512 || regions > (1L << 30)) return false;
     if ((long)std::max(std::max(c.C1, c.C2), c.Cout) * H * W * 4 >= (1L << 31)) return false;   // 32-bit byte offsets per image
-    p->nBlocks = cdiv(c.C1 + c.C2, kCB);
+    const int CinTot = c.C1 + c.C2;
+    p->tail = (CinTot > kCB && CinTot % kCB == 1) ? 1 : 0;
+    p->nBlocks = cdiv(CinTot - p->tail, kCB);
     const int wgs = std::max(1, 256 / p->nBlocks);         // workgroups per input-channel block: one per CU in all
     // vertical segments per strip: enough units to give every workgroup >= 2, segments of >= 4 regions
     int seg = 1;
@@ -326,7 +344,7 @@ static bool plan_wg16(const Wgrad16Call &c, PlanW *p) {
     p->parts = std::min(wgs, p->nUnits);
     const int SLOTS = 2 * RH + 2, PITCH = RW + 16;
     p->xcs = spread_stride(SLOTS * PITCH * 2);
-    p->ldsBytes = 2 * (size_t)p->MC * 16 * kGyStride + (size_t)kCB * p->xcs;
+    p->ldsBytes = 2 * (size_t)p->MC * 16 * kGyStride + (size_t)(kCB + 1) * p->xcs;
     p->wsBytes = (size_t)p->parts * c.Cout * (c.C1 + c.C2) * 9 * sizeof(float);
     return true;
 }
@@ -344,7 +362,7 @@ size_t wgrad16_ws_bytes(const Wgrad16Call &c) {
 long wgrad16_launches() { return g_wgrad16_launches.load(); }
 
 int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const float *gy, float *gw, void *ws,
-                size_t ws_bytes, hipStream_t s) {
+                size_t ws_bytes, sprk_reduce_item *item, hipStream_t s) {
     PlanW p;
     if (!plan_wg16(c, &p)) {
         set_error("wgrad16: geometry not eligible");
@@ -357,7 +375,7 @@ int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const flo
     Wg16Args a{};
     a.x = x; a.x2 = x2; a.gy = gy; a.partial = (float *)ws;
     a.N = c.N; a.C1 = c.C1; a.C2 = c.C2; a.H = c.H; a.W = c.W; a.Cout = c.Cout; a.padT = c.padT; a.padL = c.padL;
-    a.regX = p.regX; a.regY = p.regY; a.seg = p.seg; a.segLen = p.segLen; a.nUnits = p.nUnits; a.xcs = p.xcs;
+    a.regX = p.regX; a.regY = p.regY; a.seg = p.seg; a.segLen = p.segLen; a.nUnits = p.nUnits; a.xcs = p.xcs; a.tail = p.tail;
     static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
     a.diag = diag;
     const int dt = c.dtype & SPRK_DT_MASK;
@@ -382,9 +400,9 @@ int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const flo
     prof_end(c.kclass, s);
     if (int rc2 = check_launch("wgrad16")) return rc2;
     const long n = (long)c.Cout * (c.C1 + c.C2) * 9;
-    hipLaunchKernelGGL(wgrad16_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float *)ws, gw, n, p.parts);
     g_wgrad16_launches.fetch_add(1, std::memory_order_relaxed);
-    return check_launch("wgrad16_reduce");
+    const sprk_reduce_item it{(const float *)ws, gw, SPRK_RED_ROWS, p.parts, (int)n, 0, 0, 0};
+    return finish_or_defer(it, item, s);
 }
 
 }  // namespace sprk

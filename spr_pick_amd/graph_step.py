@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import _lib, ops
+from . import _lib, ops, torch_ops
 from .datasets import DetectionDataset
 from .feed import PinnedRing
 from .params import PipelineOutput
@@ -91,6 +91,10 @@ class FlatGrads:
         for p in self.params:
             p.grad = None
 
+    def handed_out(self, w):
+        """Has ``w``'s slice been given to an operator in this step already?"""
+        return w.data_ptr() in self._used
+
     def dest(self, w):
         key = w.data_ptr()
         v = self.views.get(key)
@@ -104,12 +108,21 @@ class FlatGrads:
         if world > 1:
             dist.all_reduce(self.flat[:self.live_numel], op=dist.ReduceOp.SUM)
 
+    # While the context is open the backward operators leave the final sums of their two-stage reductions (weight
+    # and bias gradients: ~80 five-microsecond launches per step) pending; closing it finishes them in one launch.
+    defer = True
+
     def __enter__(self):
         ops.set_grad_destinations(self)
         return self
 
     def __exit__(self, *exc):
         ops.set_grad_destinations(None)
+        if exc[0] is None:
+            if self.flat.is_cuda and torch_ops.pending_count(self.flat.device):
+                ops.flush_reductions(self.flat)
+        else:
+            torch_ops.drop_pending(self.flat.device)
         return False
 
 

@@ -60,6 +60,23 @@ def _grad_like(w):
     return torch.empty_like(w)
 
 
+def _grad_dest(w):
+    """-> (tensor, defer).  defer: the operator may leave the second stage of its sum pending (torch_ops.reduce_pending
+    finishes all of them in one launch when the flat-gradient context closes).  Only the FIRST gradient of a parameter
+    in a step is deferred: a second consumer makes autograd add the two at once, so what is pending is finished first."""
+    if _GRAD_DEST is None:
+        return torch.empty_like(w), False
+    first = not _GRAD_DEST.handed_out(w)
+    t = _GRAD_DEST.dest(w)
+    if not first:
+        flush_reductions(w)
+    return t, first and _GRAD_DEST.defer
+
+
+def flush_reductions(like):
+    _S.reduce_pending(like)
+
+
 def _ws(nbytes, like):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
 
@@ -122,15 +139,16 @@ class _Conv2dFn(torch.autograd.Function):
         up2 = 1 if ctx.up_out else 0
         if ctx.act != ACT_NONE or need_b or up2:
             want_gpre = ctx.act != ACT_NONE or bool(up2)
+            defer_b = False
             if need_b:
-                gb = _grad_like(bias)
-            out = _S.act_bwd(gy, y, ctx.act, [g.N, g.Cout, g.Hout, g.Wout], up2, want_gpre, gb)
+                gb, defer_b = _grad_dest(bias)
+            out = _S.act_bwd(gy, y, ctx.act, [g.N, g.Cout, g.Hout, g.Wout], up2, want_gpre, gb, defer_b)
             gpre = out if want_gpre else gy
         else:
             gpre = gy
         if ctx.needs_input_grad[2]:
-            gw = _grad_like(w)
-            _S.conv2d_bwd_weight(x, x2, gpre, geom_list(g), gw)
+            gw, defer_w = _grad_dest(w)
+            _S.conv2d_bwd_weight(x, x2, gpre, geom_list(g), gw, defer_w)
         need0 = ctx.needs_input_grad[0]
         need1 = x2 is not None and ctx.needs_input_grad[1]
         if need0 or need1:
@@ -234,35 +252,18 @@ class _BNTrainFn(torch.autograd.Function):
         N = x.shape[0]
         if N % groups:
             raise ValueError("batch_norm_train: batch %d is not divisible into %d groups" % (N, groups))
-        Ng = N // groups
-        ys, means, invstds = [], [], []
-        for g in range(groups):
-            y, m, iv = _S.bn_train_fwd(x[g * Ng:(g + 1) * Ng], gamma, beta, running_mean, running_var, momentum, eps, relu)
-            ys.append(y); means.append(m); invstds.append(iv)
-        y = ys[0] if groups == 1 else torch.cat(ys, 0)
+        y, mean, invstd = _S.bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, groups)
         ctx.relu, ctx.groups = relu, groups
-        ctx.save_for_backward(x, y, gamma, torch.stack(means), torch.stack(invstds), beta)
+        ctx.save_for_backward(x, y, gamma, mean, invstd, beta)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, y, gamma, mean, invstd, beta = ctx.saved_tensors
         gy = gy.contiguous()
-        N, C = x.shape[0], x.shape[1]
-        groups = ctx.groups
-        Ng = N // groups
-        if groups == 1:     # straight into the parameters' gradient tensors
-            gg, gb = _grad_like(gamma), _grad_like(beta)
-            gx = _S.bn_train_bwd(gy, x, y, gamma, mean[0], invstd[0], ctx.relu, gg, gb)
-            return gx, gg, gb, None, None, None, None, None, None
-        ggs = torch.empty((groups, C), dtype=torch.float32, device=x.device)
-        gbs = torch.empty((groups, C), dtype=torch.float32, device=x.device)
-        gxs = []
-        for g in range(groups):
-            sl = slice(g * Ng, (g + 1) * Ng)
-            gxs.append(_S.bn_train_bwd(gy[sl], x[sl], y[sl], gamma, mean[g], invstd[g], ctx.relu, ggs[g], gbs[g]))
-        gg, gb = torch.sum(ggs, 0, out=_grad_like(gamma)), torch.sum(gbs, 0, out=_grad_like(beta))
-        return torch.cat(gxs, 0), gg, gb, None, None, None, None, None, None
+        gg, gb = _grad_like(gamma), _grad_like(beta)     # straight into the parameters' gradient tensors
+        gx = _S.bn_train_bwd(gy, x, y, gamma, mean, invstd, ctx.relu, ctx.groups, gg, gb)
+        return gx, gg, gb, None, None, None, None, None, None
 
 
 def batch_norm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, relu=False, groups=1):

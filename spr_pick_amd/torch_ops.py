@@ -91,34 +91,79 @@ _register("conv2d_bwd_data", "(Tensor gy, Tensor w, int[] geom) -> Tensor", _con
           lambda gy, w, geom: gy.new_empty((geom[0], geom[1] + geom[2], geom[3], geom[4])))
 
 
-def _conv2d_bwd_weight(x, x2, gy, geom, gw):
-    """Out variant: writes into ``gw`` (a fresh tensor or the parameter's slice of the flat gradient buffer)."""
+# Pending second-stage sums (sprk_reduce_items): with defer=True the backward-weight / bias-gradient operators run only
+# their main kernel, and the ~80 small sums of a training step are finished together by ``reduce_pending``.  An entry
+# keeps its partial buffer and destination alive until then.
+_PENDING = {}
+
+
+def _pend(dev, item, *keep):
+    if item.kind != 0:
+        _PENDING.setdefault(dev.index, []).append((item, keep))
+
+
+def pending_count(dev):
+    return len(_PENDING.get(dev.index, ()))
+
+
+def _conv2d_bwd_weight(x, x2, gy, geom, gw, defer):
+    """Out variant: writes into ``gw`` (a fresh tensor or the parameter's slice of the flat gradient buffer).
+    defer: leave the sum over the workgroups' partial results to ``reduce_pending`` (gw is undefined until then)."""
     L = _lib.lib()
     g = ConvGeom(*geom)
     nb = L.sprk_conv2d_bwd_weight_ws_bytes(ctypes.byref(g))
     ws = _ws(nb, gy)
+    if defer:
+        item = _lib.ReduceItem()
+        check(L.sprk_conv2d_bwd_weight_partial(_p(x), _p(x2), _p(gy), _p(gw), ctypes.byref(g), _p(ws), nb, ctypes.byref(item),
+                                               _stream(x)), "sprk_conv2d_bwd_weight_partial")
+        _pend(gy.device, item, ws, gw)
+        return
     check(L.sprk_conv2d_bwd_weight(_p(x), _p(x2), _p(gy), _p(gw), ctypes.byref(g), _p(ws), nb, _stream(x)),
           "sprk_conv2d_bwd_weight")
 
 
-_register("conv2d_bwd_weight", "(Tensor x, Tensor? x2, Tensor gy, int[] geom, Tensor(a!) gw) -> ()", _conv2d_bwd_weight,
-          lambda x, x2, gy, geom, gw: None)
+_register("conv2d_bwd_weight", "(Tensor x, Tensor? x2, Tensor gy, int[] geom, Tensor(a!) gw, bool defer) -> ()",
+          _conv2d_bwd_weight, lambda x, x2, gy, geom, gw, defer: None)
 
 
-def _act_bwd(gy, y, act, geom4, up2, want_gpre, gbias):
-    """gpre = gy * act'(y) (2x2-summed first when up2); bias gradient into ``gbias`` when given.  Returns gpre (or gy
-    itself when no new tensor is needed)."""
+def _reduce_pending(like):
+    """Finish every pending sum of ``like``'s device in one launch per 48 items."""
+    items = _PENDING.pop(like.device.index, [])
+    if not items:
+        return
+    arr = (_lib.ReduceItem * len(items))(*[it for it, _ in items])
+    check(_lib.lib().sprk_reduce_items(arr, len(items), _stream(like)), "sprk_reduce_items")
+
+
+_register("reduce_pending", "(Tensor like) -> ()", _reduce_pending, lambda like: None)
+
+
+def drop_pending(dev):
+    """Forget pending sums without running them (error paths)."""
+    _PENDING.pop(dev.index, None)
+
+
+def _act_bwd(gy, y, act, geom4, up2, want_gpre, gbias, defer):
+    """gpre = gy * act'(y) (2x2-summed first when up2); bias gradient into ``gbias`` when given (defer: its final
+    sum is left to ``reduce_pending``).  Returns gpre (or gy itself when no new tensor is needed)."""
     L = _lib.lib()
     N, C, H, W = geom4
     gpre = _f32(gy, (N, C, H, W)) if want_gpre else None
     nb = L.sprk_act_bwd_ws_bytes(N, C, H * W)
     ws = _ws(nb, gy)
-    check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, _p(ws), nb, _stream(gy)), "sprk_act_bwd")
+    if defer and gbias is not None:
+        item = _lib.ReduceItem()
+        check(L.sprk_act_bwd_partial(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, _p(ws), nb, ctypes.byref(item),
+                                     _stream(gy)), "sprk_act_bwd_partial")
+        _pend(gy.device, item, ws, gbias)
+    else:
+        check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, _p(ws), nb, _stream(gy)), "sprk_act_bwd")
     return gpre if want_gpre else gy.new_empty(0)
 
 
-_register("act_bwd", "(Tensor gy, Tensor? y, int act, int[] nchw, int up2, bool want_gpre, Tensor(a!)? gbias) -> Tensor",
-          _act_bwd, lambda gy, y, act, nchw, up2, want_gpre, gbias: gy.new_empty(tuple(nchw) if want_gpre else (0,)))
+_register("act_bwd", "(Tensor gy, Tensor? y, int act, int[] nchw, int up2, bool want_gpre, Tensor(a!)? gbias, bool defer) -> Tensor",
+          _act_bwd, lambda gy, y, act, nchw, up2, want_gpre, gbias, defer: gy.new_empty(tuple(nchw) if want_gpre else (0,)))
 
 
 def _concat_up_bwd(gin, C1, C2, up1, x_shape, x2_shape):
@@ -226,36 +271,38 @@ _register("bn_eval_fwd", "(Tensor x, Tensor gamma, Tensor beta, Tensor running_m
                          "bool relu) -> Tensor", _bn_eval_fwd, lambda x, *a: torch.empty_like(x))
 
 
-def _bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu):
-    """One BatchNorm group: returns (y, save_mean, save_invstd); updates the running statistics in place."""
+def _bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu, groups):
+    """`groups` passes stacked along N, each with its own batch statistics: returns (y, save_mean [groups, C],
+    save_invstd [groups, C]); updates the running statistics in place, group after group."""
     L = _lib.lib()
     N, C, H, W = x.shape
-    y, mean, invstd = torch.empty_like(x), _f32(x, (C,)), _f32(x, (C,))
-    nb = L.sprk_bn_ws_bytes(N, C, H * W)
+    y, mean, invstd = torch.empty_like(x), _f32(x, (groups, C)), _f32(x, (groups, C))
+    nb = L.sprk_bn_ws_bytes(N, C, H * W, groups)
     ws = _ws(nb, x)
     check(L.sprk_bn_train_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(mean), _p(invstd),
-                              N, C, H * W, momentum, eps, int(relu), _p(ws), nb, _stream(x)), "sprk_bn_train_fwd")
+                              N, C, H * W, groups, momentum, eps, int(relu), _p(ws), nb, _stream(x)), "sprk_bn_train_fwd")
     return y, mean, invstd
 
 
 _register("bn_train_fwd", "(Tensor x, Tensor gamma, Tensor beta, Tensor(a!) running_mean, Tensor(b!) running_var, "
-                          "float momentum, float eps, bool relu) -> (Tensor, Tensor, Tensor)", _bn_train_fwd,
-          lambda x, g, *a: (torch.empty_like(x), g.new_empty(g.shape), g.new_empty(g.shape)))
+                          "float momentum, float eps, bool relu, int groups) -> (Tensor, Tensor, Tensor)", _bn_train_fwd,
+          lambda x, g, b, rm, rv, mo, eps, relu, groups: (torch.empty_like(x), g.new_empty((groups,) + tuple(g.shape)),
+                                                         g.new_empty((groups,) + tuple(g.shape))))
 
 
-def _bn_train_bwd(gy, x, y, gamma, mean, invstd, relu, ggamma, gbeta):
+def _bn_train_bwd(gy, x, y, gamma, mean, invstd, relu, groups, ggamma, gbeta):
     L = _lib.lib()
     N, C, H, W = x.shape
     gx = torch.empty_like(x)
-    nb = L.sprk_bn_ws_bytes(N, C, H * W)
+    nb = L.sprk_bn_ws_bytes(N, C, H * W, groups)
     ws = _ws(nb, x)
     check(L.sprk_bn_train_bwd(_p(gy), _p(x), _p(y), _p(gamma), _p(mean), _p(invstd), _p(gx), _p(ggamma), _p(gbeta),
-                              N, C, H * W, int(relu), _p(ws), nb, _stream(x)), "sprk_bn_train_bwd")
+                              N, C, H * W, groups, int(relu), _p(ws), nb, _stream(x)), "sprk_bn_train_bwd")
     return gx
 
 
 _register("bn_train_bwd", "(Tensor gy, Tensor x, Tensor y, Tensor gamma, Tensor mean, Tensor invstd, bool relu, "
-                          "Tensor(a!) ggamma, Tensor(b!) gbeta) -> Tensor", _bn_train_bwd,
+                          "int groups, Tensor(a!) ggamma, Tensor(b!) gbeta) -> Tensor", _bn_train_bwd,
           lambda gy, x, *a: torch.empty_like(x))
 
 

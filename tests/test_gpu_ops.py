@@ -326,6 +326,40 @@ def test_batch_norm(shape, relu):
     close(ye, F.relu(want) if relu else want, rel=1e-5, name="bn eval")
 
 
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("shape,groups", [((8, 32, 29, 29), 2), ((6, 64, 9, 9), 3), ((64, 1, 64, 64), 2), ((4, 128, 1, 1), 2)])
+def test_batch_norm_groups(shape, groups, relu):
+    """groups > 1 = the module called once per stacked pass (joint_network_v2.py runs the detector on the patches and on
+    their flipped copies): per-pass batch statistics, running averages updated pass after pass."""
+    from spr_pick_amd import ops
+    g = torch.Generator().manual_seed(13)
+    N, C = shape[0], shape[1]
+    Ng = N // groups
+    x = torch.randn(shape, generator=g) * 2 + torch.arange(N).view(N, 1, 1, 1) * 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    rm_r, rv_r = rm.double().clone(), rv.double().clone()
+    yr = torch.cat([F.batch_norm(xr[i * Ng:(i + 1) * Ng], rm_r, rv_r, gr, br, True, 0.1, 1e-5) for i in range(groups)], 0)
+    if relu:
+        yr = F.relu(yr)
+    gy = torch.randn(shape, generator=g)
+    yr.backward(gy.double())
+    d = dev()
+    xd, gd, bd = (t.to(d).requires_grad_(True) for t in (x, gamma, beta))
+    rm_d, rv_d = rm.to(d), rv.to(d)
+    y = ops.batch_norm_train(xd, gd, bd, rm_d, rv_d, 0.1, 1e-5, relu, groups=groups)
+    close(y, yr, rel=1e-5, name="bn groups y")
+    y.backward(gy.to(d))
+    close(rm_d, rm_r, rel=1e-5, name="running_mean")
+    close(rv_d, rv_r, rel=1e-5, name="running_var")
+    close(xd.grad, xr.grad, rel=1e-4, name="bn groups gx")
+    close(gd.grad, gr.grad, rel=1e-4, name="bn groups ggamma")
+    close(bd.grad, br.grad, rel=1e-4, name="bn groups gbeta")
+    with pytest.raises(Exception):
+        ops.batch_norm_train(xd.detach()[:N - 1], gd, bd, rm_d, rv_d, 0.1, 1e-5, relu, groups=groups if (N - 1) % groups else groups + 1)
+
+
 def test_reparam_sigmoid_ssdn():
     from oracle import pipeline
     from spr_pick_amd import ops
@@ -495,3 +529,106 @@ def test_conv2d_16bit_operands(case, dt):
     close(dl[2].grad, leaves[2].grad, rel=8 * u, name=name + " gw")
     if b is not None:
         close(dl[3].grad, leaves[3].grad, rel=5e-5, name=name + " gb")
+
+
+def test_reduce_items_kinds():
+    """sprk_reduce_items: the three layouts, 50 items (two launches), odd part counts, against fp64 sums and against
+    the documented order (four interleaved chains)."""
+    import ctypes
+    from spr_pick_amd import _lib, ops
+    d = dev()
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(21)
+    items, keep, want = [], [], []
+
+    def chains(t, dim):          # (s0 + s1) + (s2 + s3), s_j = sequential fp32 sum over p = j mod 4
+        parts = t.shape[dim]
+        s = []
+        for j in range(4):
+            acc = torch.zeros_like(t.select(dim, 0))
+            for p in range(j, parts, 4):
+                acc = acc + t.select(dim, p)
+            s.append(acc)
+        return (s[0] + s[1]) + (s[2] + s[3])
+
+    for i in range(50):
+        kind = 1 + i % 3
+        parts = [1, 2, 3, 5, 8, 13, 64, 37][i % 8]
+        if kind == 1:
+            n = 100 + 37 * i
+            src = torch.randn(parts, n, generator=g)
+            ref = chains(src, 0)
+            it = _lib.ReduceItem(None, None, 1, parts, n, 0, 0, 0)
+        elif kind == 2:
+            n = 5 + i
+            src = torch.randn(n, parts, generator=g)
+            ref = chains(src, 1)
+            it = _lib.ReduceItem(None, None, 2, parts, n, 0, 0, 0)
+        else:
+            K, Cout, CoutP = 9 + i, 20 + i % 7, 32
+            src = torch.randn(parts, K, CoutP, generator=g)
+            ref = chains(src, 0)[:, :Cout].t().contiguous()     # [Cout][K]
+            it = _lib.ReduceItem(None, None, 3, parts, 0, K, Cout, CoutP)
+        sd = src.to(d)
+        dst = torch.full(ref.shape, float("nan"), device=d)
+        it.src, it.dst = sd.data_ptr(), dst.data_ptr()
+        items.append(it); keep.append((sd, dst)); want.append(ref)
+    arr = (_lib.ReduceItem * len(items))(*items)
+    before = L.sprk_launch_count()
+    _lib.check(L.sprk_reduce_items(arr, len(items), ops._stream(keep[0][0])), "sprk_reduce_items")
+    assert L.sprk_launch_count() - before == 2            # 48 + 2 items
+    for (sd, dst), ref in zip(keep, want):
+        assert torch.equal(dst.cpu(), ref), "reduce_items: order of summation differs from the documented one"
+    bad = (_lib.ReduceItem * 1)(_lib.ReduceItem(keep[0][0].data_ptr(), keep[0][1].data_ptr(), 7, 1, 1, 0, 0, 0))
+    assert L.sprk_reduce_items(bad, 1, ops._stream(keep[0][0])) != 0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_deferred_reductions_match_immediate(dtype):
+    """Weight / bias gradients written through graph_step.FlatGrads (second-stage sums pending until the context
+    closes, one launch) are bit-identical to the plain operators; a parameter with two consumers is finished early."""
+    from spr_pick_amd import _lib, graph_step, ops, torch_ops
+    d = dev()
+    g = torch.Generator().manual_seed(22)
+    dt = _lib.DTYPES[dtype]
+    x = torch.randn(32, 48, 64, 64, generator=g).to(d)
+    shapes = [(48, 48, 3), (96, 48, 3), (96, 96, 1), (8, 96, 3)]
+    params = []
+    for co, ci, k in shapes:
+        params.append(torch.nn.Parameter((torch.randn(co, ci, k, k, generator=g) * 0.05).to(d)))
+        params.append(torch.nn.Parameter(torch.randn(co, generator=g).to(d)))
+
+    def net():
+        h = x
+        for i, (co, ci, k) in enumerate(shapes):
+            pad = (2, 0, 1, 1) if k == 3 else (0, 0, 0, 0)
+            h = ops.conv2d(h, params[2 * i], params[2 * i + 1], pad=pad, act=ops.ACT_LEAKY, dtype=dt)
+        # the first layer's weights once more: a second consumer of the same parameter
+        h2 = ops.conv2d(x, params[0], params[1], pad=(2, 0, 1, 1), act=ops.ACT_LEAKY, dtype=dt)
+        return h.square().mean() + h2.mean()
+
+    net().backward()
+    want = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    fg = graph_step.FlatGrads(params)
+    fg.begin_step()
+    before = _lib.lib().sprk_launch_count()
+    with fg:
+        loss = net()
+        loss.backward()
+        fg.adopt_strays()
+    assert torch_ops.pending_count(d) == 0
+    for p, w in zip(params, want):
+        assert torch.equal(p.grad, w), "deferred reduction changed a gradient (%s)" % (tuple(p.shape),)
+    fg.check_adopted()
+    # without the shared parameter every sum stays pending until the context closes
+    for p in params:
+        p.grad = None
+    fg.begin_step()
+    with fg:
+        h = ops.conv2d(x, params[0], params[1], pad=(2, 0, 1, 1), act=ops.ACT_LEAKY, dtype=dt)
+        h = ops.conv2d(h, params[2], params[3], pad=(2, 0, 1, 1), act=ops.ACT_LEAKY, dtype=dt)
+        h.square().mean().backward()
+        assert torch_ops.pending_count(d) == 4
+    assert torch_ops.pending_count(d) == 0
