@@ -228,6 +228,13 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
             if (!(a.diag & 4)) {
                 const int ga = alane + (j & 1) * gyBytes;
                 const int jrow = (j * RH) % SLOTS;
+                // byte offset of tile row (j RH + d) in the rolling buffer, d = 0 .. RH + 1 (one modulo per region)
+                int srow[RH + 2];
+#pragma unroll
+                for (int dd = 0; dd < RH + 2; ++dd) {
+                    const int t = jrow + dd;
+                    srow[dd] = (t >= SLOTS ? t - SLOTS : t) * (PITCH * 2);
+                }
 #pragma unroll
                 for (int ks = 0; ks < kRegionPx / 32; ++ks) {
                     constexpr int dummy = 0;
@@ -240,13 +247,12 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
                         av[m] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(ga + m * 16 * kGyStride + ks * 64);
 #pragma unroll
                     for (int q = 0; q < NP; ++q) {
-                        const int slot = (jrow + rr + bky[q]) % SLOTS;    // scalar
-                        int ba = blane[q] + slot * (PITCH * 2) + cc2;
-                        if (q == NP - 1 && tailWave) {                    // wave-uniform: per-lane tap row
-                            const int s0 = ((jrow + rr) % SLOTS) * (PITCH * 2), s1 = ((jrow + rr + 1) % SLOTS) * (PITCH * 2),
-                                      s2 = ((jrow + rr + 2) % SLOTS) * (PITCH * 2);
-                            ba = tlane + cc2 + (tky == 0 ? s0 : tky == 1 ? s1 : s2);
-                        }
+                        // (the 2-row regions allocate better with the modulo written out, the 4-row ones with the table)
+                        const int so = LGRW == 6 ? ((jrow + rr + bky[q]) % SLOTS) * (PITCH * 2)
+                                                 : (bky[q] == 0 ? srow[rr] : bky[q] == 1 ? srow[rr + 1] : srow[rr + 2]);   // scalar
+                        int ba = blane[q] + so + cc2;
+                        if (q == NP - 1 && tailWave)                      // wave-uniform: per-lane tap row
+                            ba = tlane + cc2 + (tky == 0 ? srow[rr] : tky == 1 ? srow[rr + 1] : srow[rr + 2]);
                         bv[q] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)ba;
                     }
 #pragma unroll

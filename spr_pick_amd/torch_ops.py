@@ -93,7 +93,8 @@ _register("conv2d_bwd_data", "(Tensor gy, Tensor w, int[] geom) -> Tensor", _con
 
 # Pending second-stage sums (sprk_reduce_items): with defer=True the backward-weight / bias-gradient operators run only
 # their main kernel, and the ~80 small sums of a training step are finished together by ``reduce_pending``.  An entry
-# keeps its partial buffer and destination alive until then.
+# keeps its partial buffer alive until then; the destination must be kept alive by the caller (ops defers only
+# gradients that live in graph_step.FlatGrads' buffer).
 _PENDING = {}
 
 
@@ -117,7 +118,7 @@ def _conv2d_bwd_weight(x, x2, gy, geom, gw, defer):
         item = _lib.ReduceItem()
         check(L.sprk_conv2d_bwd_weight_partial(_p(x), _p(x2), _p(gy), _p(gw), ctypes.byref(g), _p(ws), nb, ctypes.byref(item),
                                                _stream(x)), "sprk_conv2d_bwd_weight_partial")
-        _pend(gy.device, item, ws, gw)
+        _pend(gy.device, item, ws)     # not gw: autograd adopts a gradient tensor only while nobody else holds it
         return
     check(L.sprk_conv2d_bwd_weight(_p(x), _p(x2), _p(gy), _p(gw), ctypes.byref(g), _p(ws), nb, _stream(x)),
           "sprk_conv2d_bwd_weight")
@@ -156,7 +157,7 @@ def _act_bwd(gy, y, act, geom4, up2, want_gpre, gbias, defer):
         item = _lib.ReduceItem()
         check(L.sprk_act_bwd_partial(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, _p(ws), nb, ctypes.byref(item),
                                      _stream(gy)), "sprk_act_bwd_partial")
-        _pend(gy.device, item, ws, gbias)
+        _pend(gy.device, item, ws)
     else:
         check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, _p(ws), nb, _stream(gy)), "sprk_act_bwd")
     return gpre if want_gpre else gy.new_empty(0)
