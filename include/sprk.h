@@ -198,6 +198,16 @@ int sprk_reparam_bwd(const float *gz, const float *out_stats, const float *eps, 
 /* _sigmoid: clamp(sigmoid(x), 1e-4, 1-1e-4)  (denoiser_v2.py:32-34) */
 int sprk_sigmoid_clamp_fwd(const float *x, float *p, long n, void *stream);
 int sprk_sigmoid_clamp_bwd(const float *gp, const float *x, float *gx, long n, void *stream);
+/* PU detection loss and its gradient in one launch (utils/losses.py:303-349: BCE on the labelled patches + slack *
+ * binomial generalised-expectation penalty on the unlabelled ones):
+ *   y[i] >= 0: labelled with target y[i];  y[i] == -1: unlabelled;  N = number of unlabelled, n_lab of labelled
+ *   cls = sum_lab -(y log p + (1-y) log(1-p)) / max(n_lab, 1)
+ *   mu = sum_unl p, var = sum_unl p (1-p);  q = softmax_k(-(mu - k)^2 / (2 (var + 1e-7))), k = 0..N
+ *   loss[0] = cls - slack * sum_k log_binom[N][k] q[k];   gp[i] = d loss / d p[i]
+ * log_binom: [B+1][B+1] table, row N = binom.logpmf(0..N; N, tau) (the host computes it once per (B, tau)).
+ * p in (0, 1) (sigmoid_clamp output).  One workgroup; sums in a fixed order. */
+int sprk_pu_loss(const float *p, const float *y, const float *log_binom, int B, float slack,
+                 float *loss, float *gp, void *stream);
 /* SSDN gaussian likelihood + posterior mean (denoiser_v2.py:449-462, :514):
  *   var_x = A^2, var_n = s^2, var_y = var_x + var_n
  *   nll = (x-mu)^2/var_y + log var_y - 0.05 s      -> loss[b] = mean over HW

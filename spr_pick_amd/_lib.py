@@ -68,6 +68,7 @@ _SIGS = {
     "sprk_bn_train_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "sprk_reparam_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_vp]),
     "sprk_reparam_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_vp]),
+    "sprk_pu_loss": (c_i, [c_f, c_f, c_f, c_i, ctypes.c_float, c_f, c_f, c_vp]),
     "sprk_sigmoid_clamp_fwd": (c_i, [c_f, c_f, ctypes.c_long, c_vp]),
     "sprk_sigmoid_clamp_bwd": (c_i, [c_f, c_f, c_f, ctypes.c_long, c_vp]),
     "sprk_ssdn_ws_bytes": (c_sz, [c_i, c_i]),

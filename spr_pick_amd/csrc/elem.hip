@@ -283,6 +283,87 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     return r;
 }
 
+// ---- PU detection loss (utils/losses.py:303-349), value and gradient in one workgroup ------------------------
+__device__ __forceinline__ float block_max(float v, float *red) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int w = kSsdnBlk / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(kSsdnBlk) void pu_loss_kernel(const float *__restrict__ p, const float *__restrict__ y,
+                                                           const float *__restrict__ log_binom, int B, float slack,
+                                                           float *__restrict__ loss, float *__restrict__ gp) {
+    __shared__ float red[kSsdnBlk];
+    const int tid = threadIdx.x;
+    float nl = 0.f, nu = 0.f, bce = 0.f, mu = 0.f, var = 0.f;
+    for (int i = tid; i < B; i += kSsdnBlk) {
+        const float pi = p[i], yi = y[i];
+        if (yi >= 0.f) {
+            nl += 1.f;
+            bce -= yi * logf(pi) + (1.f - yi) * logf(1.f - pi);
+        } else if (yi == -1.f) {
+            nu += 1.f;
+            mu += pi;
+            var += pi * (1.f - pi);
+        }
+    }
+    nl = block_sum(nl, red);
+    nu = block_sum(nu, red);
+    bce = block_sum(bce, red);
+    mu = block_sum(mu, red);
+    var = block_sum(var, red);
+    const int N = (int)nu;
+    const float inv_lab = 1.f / fmaxf(nl, 1.f);
+    const float iv = 1.f / (var + 1e-7f);
+    const float *lb = log_binom + (long)N * (B + 1);
+    // softmax over k = 0..N of -(mu - k)^2 / (2 (var + 1e-7)), and the sums its gradient needs
+    float mx = -INFINITY;
+    for (int k = tid; k <= N; k += kSsdnBlk) {
+        const float dk = mu - (float)k;
+        mx = fmaxf(mx, -0.5f * dk * dk * iv);
+    }
+    mx = block_max(mx, red);
+    float Z = 0.f, A = 0.f, B1 = 0.f, B2 = 0.f, C1 = 0.f, C2 = 0.f;
+    for (int k = tid; k <= N; k += kSsdnBlk) {
+        const float dk = mu - (float)k;
+        const float e = expf(-0.5f * dk * dk * iv - mx);
+        const float l = lb[k];
+        const float d1 = -dk * iv;                 // d logit_k / d mu
+        const float d2 = 0.5f * dk * dk * iv * iv; // d logit_k / d var
+        Z += e;
+        A += e * l;
+        B1 += e * l * d1;
+        B2 += e * d1;
+        C1 += e * l * d2;
+        C2 += e * d2;
+    }
+    Z = block_sum(Z, red);
+    A = block_sum(A, red);
+    B1 = block_sum(B1, red);
+    B2 = block_sum(B2, red);
+    C1 = block_sum(C1, red);
+    C2 = block_sum(C2, red);
+    const float S = A / Z;                         // sum_k log_binom_k q_k
+    const float g_mu = -slack * (B1 - S * B2) / Z; // d loss / d mu
+    const float g_var = -slack * (C1 - S * C2) / Z;
+    if (tid == 0) loss[0] = bce * inv_lab - slack * S;
+    for (int i = tid; i < B; i += kSsdnBlk) {
+        const float pi = p[i], yi = y[i];
+        float g = 0.f;
+        if (yi >= 0.f)
+            g = -(yi / pi - (1.f - yi) / (1.f - pi)) * inv_lab;
+        else if (yi == -1.f)
+            g = g_mu + g_var * (1.f - 2.f * pi);
+        gp[i] = g;
+    }
+}
+
 // grid (nblk, B); partial[b*nblk + blk] = sum of nll over the block's pixels
 __global__ __launch_bounds__(kSsdnBlk) void ssdn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ o,
                                                             const float *__restrict__ ns, float *__restrict__ partial,
@@ -419,6 +500,13 @@ int sprk_sigmoid_clamp_bwd(const float *gp, const float *x, float *gx, long n, v
     hipLaunchKernelGGL(sigmoid_clamp_bwd_kernel, dim3(sprk::ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, gp, x, gx,
                        n);
     return sprk::check_launch("sigmoid_clamp_bwd");
+}
+
+int sprk_pu_loss(const float *p, const float *y, const float *log_binom, int B, float slack, float *loss, float *gp,
+                 void *stream) {
+    SPRK_REQUIRE(p && y && log_binom && loss && gp && B > 0 && B < (1 << 20), "pu_loss: bad arguments");
+    hipLaunchKernelGGL(pu_loss_kernel, dim3(1), dim3(kSsdnBlk), 0, (hipStream_t)stream, p, y, log_binom, B, slack, loss, gp);
+    return sprk::check_launch("pu_loss");
 }
 
 size_t sprk_ssdn_ws_bytes(int B, int HW) { return (size_t)B * ssdn_nblk(HW) * sizeof(float); }

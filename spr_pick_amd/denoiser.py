@@ -57,6 +57,16 @@ class PuLoss(nn.Module):
         return self._tables[key]
 
     def forward(self, tau, p, y, slack=4.0):
+        """One launch on the GPU (ops.pu_loss: loss and d loss / d p together); the mask form below states the same
+        maths in torch operators (~40 five-microsecond launches forward and as many backward) and is what the CPU
+        tests pin against the oracle."""
+        if not p.is_cuda:
+            raise RuntimeError("PuLoss runs on the GPU only; mask_form() is the torch statement for CPU checks")
+        y = y.reshape(-1).to(device=p.device, dtype=torch.float32)
+        table, _ = self._log_binom_table(p.numel(), tau, p.device)
+        return ops.pu_loss(p, y, table, slack)
+
+    def mask_form(self, tau, p, y, slack=4.0):
         p = p.reshape(-1)
         y = y.reshape(-1).to(device=p.device, dtype=torch.float32)
         B = p.shape[0]

@@ -318,6 +318,29 @@ def sigmoid_clamp(x):
     return _SigmoidClampFn.apply(x)
 
 
+class _PuLossFn(torch.autograd.Function):
+    """PU detection loss (utils/losses.py:303-349); value and gradient come out of the same launch."""
+
+    @staticmethod
+    def forward(ctx, p, y, log_binom, slack):
+        _need_gpu(p, y, log_binom)
+        loss, gp = _S.pu_loss(p.contiguous().reshape(-1), y.contiguous().reshape(-1), log_binom.contiguous(), float(slack))
+        ctx.save_for_backward(gp)
+        ctx.p_shape = p.shape
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        (gp,) = ctx.saved_tensors
+        return (gp * gl).reshape(ctx.p_shape), None, None, None
+
+
+def pu_loss(p, y, log_binom, slack=4.0):
+    """p: scores in (0, 1); y: labels (>= 0 labelled, -1 unlabelled), fp32; log_binom: [B+1, B+1] table whose row N is
+    binom.logpmf(0..N; N, tau)."""
+    return _PuLossFn.apply(p, y, log_binom, slack)
+
+
 class _SsdnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, out_stats, noise_std):

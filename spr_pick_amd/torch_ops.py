@@ -225,6 +225,21 @@ _simple("sigmoid_clamp_bwd", "(Tensor gp, Tensor x) -> Tensor", "sprk_sigmoid_cl
         lambda a, y: (_p(a[0]), _p(a[1]), _p(y), a[1].numel()))
 
 
+def _pu_loss(p, y, log_binom, slack):
+    """-> (loss [1], d loss / d p [B]) in one launch."""
+    B = p.numel()
+    if log_binom.shape != (B + 1, B + 1) or y.numel() != B:
+        raise ValueError("pu_loss: table %s / labels %d do not match %d scores" % (tuple(log_binom.shape), y.numel(), B))
+    loss, gp = _f32(p, (1,)), _f32(p, (B,))
+    check(_lib.lib().sprk_pu_loss(_p(p), _p(y), _p(log_binom), B, ctypes.c_float(slack), _p(loss), _p(gp), _stream(p)),
+          "sprk_pu_loss")
+    return loss, gp
+
+
+_register("pu_loss", "(Tensor p, Tensor y, Tensor log_binom, float slack) -> (Tensor, Tensor)", _pu_loss,
+          lambda p, y, t, slack: (p.new_empty((1,)), p.new_empty((p.numel(),))))
+
+
 def _ssdn_fwd(x, out_stats, noise_std):
     L = _lib.lib()
     B, _, H, W = out_stats.shape

@@ -632,3 +632,37 @@ def test_deferred_reductions_match_immediate(dtype):
         h.square().mean().backward()
         assert torch_ops.pending_count(d) == 4
     assert torch_ops.pending_count(d) == 0
+
+
+def test_pu_loss_kernel_every_label_mix():
+    """ops.pu_loss (one launch: value + gradient) against the oracle's statement of utils/losses.py:303-349 and the
+    gradient autograd derives from the torch mask form, for mixed, all-unlabelled, all-labelled, single-unlabelled
+    batches and a batch longer than the workgroup."""
+    from oracle import pipeline
+    from spr_pick_amd.denoiser import PuLoss
+    d = dev()
+    g = torch.Generator().manual_seed(23)
+    pu = PuLoss()
+    for B, labels in ((16, None), (16, "none"), (8, "all"), (8, "one_unl"), (64, None), (700, None)):
+        p = torch.rand(B, 1, 1, 1, generator=g) * 0.98 + 0.01
+        y = torch.where(torch.rand(B, 1, generator=g) < 0.3, torch.rand(B, 1, generator=g), torch.full((B, 1), -1.0))
+        if labels == "none":
+            y = torch.full((B, 1), -1.0)
+        elif labels == "all":
+            y = torch.rand(B, 1, generator=g)
+        elif labels == "one_unl":
+            y = torch.rand(B, 1, generator=g)
+            y[3] = -1.0
+        for tau in (0.01, 0.2):
+            pr = p.double().requires_grad_(True)
+            want = pu.mask_form(tau, pr, y.double())
+            want.backward()
+            oracle_val = pipeline.pu_loss(tau, p, y)
+            pd = p.to(d).requires_grad_(True)
+            got = pu(tau, pd, y.to(d))
+            (got * 1.5).backward()
+            assert abs(float(got) - float(oracle_val)) <= 2e-5 * abs(float(oracle_val)) + 1e-5, (B, labels, tau)
+            close(got, want.float(), rel=2e-5, name="pu loss %s %s" % (B, labels))
+            close(pd.grad, 1.5 * pr.grad.float(), rel=2e-4, name="pu grad %s %s %s" % (B, labels, tau))
+    with pytest.raises(Exception):
+        pu(0.01, torch.rand(4), torch.zeros(4))       # CPU tensors: the product path is the GPU kernel

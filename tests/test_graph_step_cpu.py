@@ -86,7 +86,7 @@ def test_pu_loss_mask_form_matches_oracle_on_every_label_mix():
             y[3] = -1.0
         for tau in (0.01, 0.2):
             want = pipeline.pu_loss(tau, p, y)
-            got = pu(tau, p, y)
+            got = pu.mask_form(tau, p, y)
             assert torch.allclose(got, want, rtol=2e-5, atol=1e-6), (B, labels, tau, float(got), float(want))
 
 

@@ -66,10 +66,10 @@ def test_pu_loss_matches_oracle():
     p = torch.rand(16, 1, 1, 1, generator=g) * 0.98 + 0.01
     y = torch.tensor([1.0, -1, -1, 0.3, -1, -1, -1, 0.0, -1, -1, -1, -1, 1.0, -1, -1, -1]).reshape(16, 1)
     want = pipeline.pu_loss(0.01, p, y)
-    got = PuLoss()(0.01, p, y)
+    got = PuLoss().mask_form(0.01, p, y)
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
     y2 = torch.full((16, 1), -1.0)
-    assert torch.allclose(PuLoss()(0.05, p, y2), pipeline.pu_loss(0.05, p, y2), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(PuLoss().mask_form(0.05, p, y2), pipeline.pu_loss(0.05, p, y2), rtol=1e-5, atol=1e-6)
 
 
 def test_pick_filter_and_writer(tmp_path):
