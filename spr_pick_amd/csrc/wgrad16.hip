@@ -299,6 +299,148 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     }
 }
 
+
+// ---- 1x1 layers (the 384 -> 384 -> 96 head of the blind-spot network) ----------------------------------------------
+//   dW[cout][cin] = sum over images and pixels of gy[n][cout][px] * x[n][cin][px]
+// No taps and no halo: both operands are [channel][64 pixels] tiles (16-bit, rows of 144 bytes: conflict-free
+// ds_read_b128 for the 16 channels x 4 pixel groups of a fragment).  The 8 waves form a WM x WN grid over a
+// (WM MC 16) x (WN NC 16) block of dW — 192 x 192 (Cout > 96: x and gy are each read Cout/192 resp. Cin/192 times) or
+// 96 x 384 (gy and x read once) — 18 accumulator tiles per wave, 9 LDS reads per 18 MFMAs.  The kernel is HBM-bound
+// (two MFMA k-steps per 96 KB of fp32 input per workgroup), so the tile shape is chosen for the fewest re-reads.
+// Regions of 64 pixels are dealt to the workgroups in contiguous runs; the next region's 12 x 16 bytes per lane are
+// in flight under the current region's MFMAs, converted and written to the other LDS stage.
+struct Wg1Args {
+    const float *x, *gy;
+    float *partial;          // [parts][Cout][Cin]
+    int N, Cin, Cout, HW;
+    int regPerImg, nRegions, perPart;
+    int diag;
+};
+
+template <typename T, int WM, int MC, int NC>
+__global__ __launch_bounds__(kWgThreads) void wgrad16_1x1_kernel(const Wg1Args a) {
+    using V8 = typename OpW<T>::v8;
+    typedef const __attribute__((address_space(3))) V8 *lds_v8p;
+    constexpr int WN = 8 / WM;
+    constexpr int CO = WM * MC * 16, CI = WN * NC * 16;
+    constexpr int kPx = 64, kRow = kPx * 2 + 16;               // bytes per channel row of a tile
+    constexpr int GN = CO * 16 / kWgThreads, XN = CI * 16 / kWgThreads;   // 16-byte items per thread
+    constexpr int gyBytes = CO * kRow, xBytes = CI * kRow;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int co0 = blockIdx.y * CO, ci0 = blockIdx.z * CI;
+    const int ldsGy = lds_addr(smem), ldsX = ldsGy + 2 * gyBytes;
+
+    typedef unsigned u32x4 __attribute__((__vector_size__(16)));
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u16x4 *lds_u16x4w;
+    auto cvt4 = [&](const u32x4 &v) {
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+        t4 r;
+        r[0] = (T)__uint_as_float(e0);
+        r[1] = (T)__uint_as_float(e1);
+        r[2] = (T)__uint_as_float(e2);
+        r[3] = (T)__uint_as_float(e3);
+        return __builtin_bit_cast(u16x4, r);
+    };
+    // item i of this thread: channel row (tid >> 4) + 32 i, pixel group tid & 15
+    const int row0 = tid >> 4, g4 = tid & 15;
+    const int goff0 = ((co0 + row0) * a.HW + g4 * 4) * 4, xoff0 = ((ci0 + row0) * a.HW + g4 * 4) * 4;
+    const int rstep = 32 * a.HW * 4;
+    const int lrow = row0 * kRow + g4 * 8;
+    const int gyLim = (a.diag & 1) ? 0 : a.Cout - co0, xLim = (a.diag & 1) ? 0 : a.Cin - ci0;
+    u32x4 fg[GN], fx[XN];
+    auto fetch = [&](const rsrc_t rg, const rsrc_t rx, int org) {
+#pragma unroll
+        for (int i = 0; i < GN; ++i)
+            fg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, row0 + 32 * i < gyLim ? goff0 + i * rstep : (int)0x80000000, org, 0);
+#pragma unroll
+        for (int i = 0; i < XN; ++i)
+            fx[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, row0 + 32 * i < xLim ? xoff0 + i * rstep : (int)0x80000000, org, 0);
+    };
+    auto store = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < GN; ++i)
+            *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(ldsGy + b * gyBytes + lrow + i * 32 * kRow) = cvt4(fg[i]);
+#pragma unroll
+        for (int i = 0; i < XN; ++i)
+            *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(ldsX + b * xBytes + lrow + i * 32 * kRow) = cvt4(fx[i]);
+    };
+    f32x4 acc[MC][NC];
+#pragma unroll
+    for (int m = 0; m < MC; ++m)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int alane = ldsGy + (wm * MC * 16 + l15) * kRow + kq * 16;
+    const int blane = ldsX + (wn * NC * 16 + l15) * kRow + kq * 16;
+
+    const int r0 = blockIdx.x * a.perPart, r1 = min(a.nRegions, r0 + a.perPart);
+    auto rsrcs = [&](int r, rsrc_t &rg, rsrc_t &rx, int &org) {
+        const int n = r / a.regPerImg, pb = r - n * a.regPerImg;
+        rg = make_rsrc(a.gy + (long)n * a.Cout * a.HW);
+        rx = make_rsrc(a.x + (long)n * a.Cin * a.HW);
+        org = pb * kPx * 4;
+    };
+    if (r0 < r1) {
+        rsrc_t rg, rx;
+        int org;
+        rsrcs(r0, rg, rx, org);
+        fetch(rg, rx, org);
+        store(0);
+    }
+    for (int r = r0; r < r1; ++r) {
+        __syncthreads();                                   // region r's tiles are complete; the other stage is free
+        const int b = (r - r0) & 1;
+        const bool more = r + 1 < r1;
+        if (more) {
+            rsrc_t rg, rx;
+            int org;
+            rsrcs(r + 1, rg, rx, org);
+            fetch(rg, rx, org);
+        }
+        if (!(a.diag & 4)) {
+#pragma unroll
+            for (int ks = 0; ks < kPx / 32; ++ks) {
+                V8 av[MC], bv[NC];
+#pragma unroll
+                for (int m = 0; m < MC; ++m)
+                    av[m] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(alane + b * gyBytes + m * 16 * kRow + ks * 64);
+#pragma unroll
+                for (int n = 0; n < NC; ++n)
+                    bv[n] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(blane + b * xBytes + n * 16 * kRow + ks * 64);
+#pragma unroll
+                for (int m = 0; m < MC; ++m)
+#pragma unroll
+                    for (int n = 0; n < NC; ++n) acc[m][n] = OpW<T>::mma(av[m], bv[n], acc[m][n]);
+            }
+        }
+        if (more) store(b ^ 1);
+    }
+    // partial dW of this workgroup: D layout col(n = cin) = lane & 15, row(m = cout) = (lane >> 4) * 4 + reg
+    float *part = a.partial + (long)blockIdx.x * a.Cout * a.Cin;
+#pragma unroll
+    for (int m = 0; m < MC; ++m)
+#pragma unroll
+        for (int n = 0; n < NC; ++n) {
+            const int ci = ci0 + (wn * NC + n) * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + (wm * MC + m) * 16 + kq * 4 + j;
+                if (co < a.Cout && ci < a.Cin) part[(long)co * a.Cin + ci] = acc[m][n][j];
+            }
+        }
+}
+
+struct Plan1 {
+    int wide;                // 1: 192 x 192 blocks, 0: 96 x 384
+    int coBlocks, ciBlocks, parts, perPart, regPerImg, nRegions;
+    size_t ldsBytes, wsBytes;
+};
+
 struct PlanW {
     int MC, lgRW, regX, regY, seg, segLen, nUnits, xcs, parts, nBlocks, tail;
     size_t ldsBytes, wsBytes;
@@ -355,14 +497,84 @@ static bool plan_wg16(const Wgrad16Call &c, PlanW *p) {
     return true;
 }
 
+static bool plan_wg1x1(const Wgrad16Call &c, Plan1 *p) {
+    const int dt = c.dtype & SPRK_DT_MASK;
+    if (dt != SPRK_DT_BF16 && dt != SPRK_DT_F16) return false;
+    static const int on = getenv("SPRK_WGRAD16_1X1") ? atoi(getenv("SPRK_WGRAD16_1X1")) : 1;   // debug: 0 = fp32 kernel
+    if (!on) return false;
+    if (c.KH != 1 || c.KW != 1 || c.stride != 1 || c.dil != 1 || c.up1 || c.C2 != 0) return false;
+    if (c.padL != 0 || c.padT != 0 || c.Hout != c.H || c.Wout != c.W) return false;
+    const int HW = c.H * c.W, Cin = c.C1;
+    if (HW % 64 || c.Cout < 33 || Cin < 97) return false;
+    if ((long)std::max(Cin, c.Cout) * HW * 4 >= (1L << 31)) return false;       // 32-bit byte offsets inside an image
+    p->regPerImg = HW / 64;
+    const long regions = (long)c.N * p->regPerImg;
+    if (regions < 1024 || regions > (1L << 30)) return false;
+    p->nRegions = (int)regions;
+    p->wide = c.Cout > 96 ? 1 : 0;
+    const int CO = p->wide ? 192 : 96, CI = p->wide ? 192 : 384;
+    p->coBlocks = cdiv(c.Cout, CO);
+    p->ciBlocks = cdiv(Cin, CI);
+    const int blocks = p->coBlocks * p->ciBlocks;
+    if (blocks > 64) return false;
+    const int parts = std::max(1, 256 / blocks);                                // one workgroup per CU in all
+    p->perPart = cdiv(regions, parts);
+    p->parts = cdiv(regions, p->perPart);
+    p->ldsBytes = 2 * (size_t)(CO + CI) * (64 * 2 + 16);
+    p->wsBytes = (size_t)p->parts * c.Cout * Cin * sizeof(float);
+    return true;
+}
+
 bool wgrad16_eligible(const Wgrad16Call &c) {
     PlanW p;
-    return plan_wg16(c, &p);
+    Plan1 p1;
+    return plan_wg16(c, &p) || plan_wg1x1(c, &p1);
 }
 
 size_t wgrad16_ws_bytes(const Wgrad16Call &c) {
     PlanW p;
-    return plan_wg16(c, &p) ? p.wsBytes : 0;
+    Plan1 p1;
+    return plan_wg16(c, &p) ? p.wsBytes : plan_wg1x1(c, &p1) ? p1.wsBytes : 0;
+}
+
+static int wgrad16_run_1x1(const Wgrad16Call &c, const Plan1 &p, const float *x, const float *gy, float *gw, void *ws,
+                           size_t ws_bytes, sprk_reduce_item *item, hipStream_t s) {
+    if (ws_bytes < p.wsBytes || !ws) {
+        set_error("wgrad16 (1x1): workspace too small (%zu < %zu)", ws_bytes, p.wsBytes);
+        return SPRK_EWORKSPACE;
+    }
+    if ((((uintptr_t)x | (uintptr_t)gy) & 15) != 0) {
+        set_error("wgrad16 (1x1): tensors must be 16-byte aligned");
+        return SPRK_EINVAL;
+    }
+    Wg1Args a{};
+    a.x = x; a.gy = gy; a.partial = (float *)ws;
+    a.N = c.N; a.Cin = c.C1; a.Cout = c.Cout; a.HW = c.H * c.W;
+    a.regPerImg = p.regPerImg; a.nRegions = p.nRegions; a.perPart = p.perPart;
+    static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
+    a.diag = diag;
+    dim3 grid(p.parts, p.coBlocks, p.ciBlocks);
+    auto go = [&](auto kernel) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)p.ldsBytes) != hipSuccess) {
+            set_error("wgrad16 (1x1): cannot reserve %zu bytes of LDS", p.ldsBytes);
+            return (int)SPRK_ELAUNCH;
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(kWgThreads), p.ldsBytes, s, a);
+        return (int)SPRK_OK;
+    };
+    auto pick = [&](auto tag) {
+        using T = decltype(tag);
+        return p.wide ? go(wgrad16_1x1_kernel<T, 4, 3, 6>) : go(wgrad16_1x1_kernel<T, 2, 3, 6>);
+    };
+    prof_begin(c.kclass, c.flops, s);
+    const int rc = (c.dtype & SPRK_DT_MASK) == SPRK_DT_BF16 ? pick(__bf16{}) : pick(_Float16{});
+    if (rc) return rc;
+    prof_end(c.kclass, s);
+    if (int rc2 = check_launch("wgrad16_1x1")) return rc2;
+    g_wgrad16_launches.fetch_add(1, std::memory_order_relaxed);
+    const sprk_reduce_item it{(const float *)ws, gw, SPRK_RED_ROWS, p.parts, c.Cout * c.C1, 0, 0, 0};
+    return finish_or_defer(it, item, s);
 }
 
 long wgrad16_launches() { return g_wgrad16_launches.load(); }
@@ -371,6 +583,8 @@ int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const flo
                 size_t ws_bytes, sprk_reduce_item *item, hipStream_t s) {
     PlanW p;
     if (!plan_wg16(c, &p)) {
+        Plan1 p1;
+        if (plan_wg1x1(c, &p1)) return wgrad16_run_1x1(c, p1, x, gy, gw, ws, ws_bytes, item, s);
         set_error("wgrad16: geometry not eligible");
         return SPRK_EINVAL;
     }
