@@ -159,7 +159,18 @@ class _Conv2dFn(torch.autograd.Function):
                 gd = ConvGeom(g.N, g.C1, 0, g.Hin, g.Win, g.up1, g.Cout, g.Hout, g.Wout, g.KH, g.KW, g.stride, g.dil,
                               g.pad_top, g.pad_left, g.dtype)
                 wd = w[:, :g.C1].contiguous()
-            gin = _S.conv2d_bwd_data(gpre, wd, geom_list(gd))
+            gsrc = gpre
+            if gd.stride > 1 and not (gd.dtype & _lib.DT_NAIVE):
+                # strided layers (the detector's down-sampling convolutions): the gradient w.r.t. the input is the
+                # stride-1 backward-data of gy with stride - 1 zeros between its samples — the MFMA kernel on a
+                # zero-stuffed copy (tiny tensors) instead of the direct kernel
+                st = gd.stride
+                H1, W1 = (gd.Hout - 1) * st + 1, (gd.Wout - 1) * st + 1
+                gsrc = gpre.new_zeros((gd.N, gd.Cout, H1, W1))
+                gsrc[:, :, ::st, ::st] = gpre
+                gd = ConvGeom(gd.N, gd.C1, gd.C2, gd.Hin, gd.Win, gd.up1, gd.Cout, H1, W1, gd.KH, gd.KW, 1, gd.dil,
+                              gd.pad_top, gd.pad_left, gd.dtype)
+            gin = _S.conv2d_bwd_data(gsrc, wd, geom_list(gd))
             if gd.C2 == 0 and not gd.up1:
                 gx = gin
             else:
