@@ -63,7 +63,7 @@ struct Wg16Args {
     int diag;
 };
 
-// LGRW: log2 of the region width (6: 2 rows x 64 columns, 5: 4 rows x 32 columns).
+// LGRW: log2 of the region width (6: 2 rows x 64 columns, 5: 4 rows x 32 columns, 4: 8 rows x 16 columns).
 // The x tile is a ROLLING window of SLOTS = 2 RH + 2 tile rows per channel: consecutive regions of a strip share RH + 2
 // - RH = 2 halo rows... precisely: region j reads tile rows j RH .. j RH + RH + 1 and only the RH rows below are new, so
 // x is fetched once (the first version re-fetched the halo rows of every region: 2x the bytes at 2-row regions).
@@ -185,6 +185,10 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     for (int m = 0; m < MC; ++m)
 #pragma unroll
         for (int q = 0; q < NP; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // a k-step is 32 consecutive region pixels: one row piece (regions >= 32 wide) or two 16-pixel rows (LGRW = 4),
+    // where the lane's pixel group kq sits in row kq >> 1 at column 8 (kq & 1)
+    const int kcol = LGRW == 4 ? (kq & 1) * 8 : kq * 8;
+    const bool krow1 = LGRW == 4 && (kq >> 1);
     int blane[NP], bky[NP];   // lane part of the B address (channel, tap column, pixel group) | tap row (wave-uniform)
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
@@ -192,12 +196,12 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
         const int it = pr / 9, tap = pr - it * 9;
         const int ky = tap / 3, kx = tap - ky * 3;
         bky[q] = __builtin_amdgcn_readfirstlane(ky);
-        blane[q] = ldsX + (it * 16 + l15) * a.xcs + (8 + kx - a.padL + kq * 8) * 2;
+        blane[q] = ldsX + (it * 16 + l15) * a.xcs + (8 + kx - a.padL + kcol) * 2;
     }
     const int alane = ldsGy + l15 * kGyStride + kq * 16;
     // tail tile: lane's tap = min(l & 15, 8) (columns 9..15 of D are not stored)
     const int ttap = min(l15, 8), tky = ttap / 3, tkx = ttap - tky * 3;
-    const int tlane = ldsX + kCB * a.xcs + (8 + tkx - a.padL + kq * 8) * 2;
+    const int tlane = ldsX + kCB * a.xcs + (8 + tkx - a.padL + kcol) * 2;
 
     for (int u = blockIdx.x; u < a.nUnits; u += gridDim.x) {
         const int sgi = u % a.seg;
@@ -248,11 +252,20 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
 #pragma unroll
                     for (int q = 0; q < NP; ++q) {
                         // (the 2-row regions allocate better with the modulo written out, the 4-row ones with the table)
-                        const int so = LGRW == 6 ? ((jrow + rr + bky[q]) % SLOTS) * (PITCH * 2)
-                                                 : (bky[q] == 0 ? srow[rr] : bky[q] == 1 ? srow[rr + 1] : srow[rr + 2]);   // scalar
+                        int so = LGRW == 6 ? ((jrow + rr + bky[q]) % SLOTS) * (PITCH * 2)
+                                           : (bky[q] == 0 ? srow[rr] : bky[q] == 1 ? srow[rr + 1] : srow[rr + 2]);   // scalar
+                        if constexpr (LGRW == 4) {                        // second row of the k-step: per-lane select
+                            const int so1 = bky[q] == 0 ? srow[rr + 1] : bky[q] == 1 ? srow[rr + 2] : srow[rr + 3];
+                            so = krow1 ? so1 : so;
+                        }
                         int ba = blane[q] + so + cc2;
-                        if (q == NP - 1 && tailWave)                      // wave-uniform: per-lane tap row
-                            ba = tlane + cc2 + (tky == 0 ? srow[rr] : tky == 1 ? srow[rr + 1] : srow[rr + 2]);
+                        if (q == NP - 1 && tailWave) {                    // wave-uniform: per-lane tap row
+                            int t0 = srow[rr], t1 = srow[rr + 1], t2 = srow[rr + 2];
+                            if constexpr (LGRW == 4) {
+                                if (krow1) t0 = srow[rr + 1], t1 = srow[rr + 2], t2 = srow[rr + 3];
+                            }
+                            ba = tlane + cc2 + (tky == 0 ? t0 : tky == 1 ? t1 : t2);
+                        }
                         bv[q] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)ba;
                     }
 #pragma unroll
@@ -470,7 +483,7 @@ static bool plan_wg16(const Wgrad16Call &c, PlanW *p) {
     const int W = c.W, H = c.H;
     int RW;
     if (W % 64 == 0) RW = 64;
-    else if (W == 32) RW = 32;
+    else if (W == 32 || W == 16) RW = W;
     else return false;
     const int RH = kRegionPx / RW;
     if (H % RH) return false;
@@ -612,7 +625,8 @@ int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const flo
     auto pick = [&](auto tag) {
         using T = decltype(tag);
         if (p.lgRW == 6) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 6>) : go(wgrad16_kernel<T, 3, 6>);
-        return p.MC == 6 ? go(wgrad16_kernel<T, 6, 5>) : go(wgrad16_kernel<T, 3, 5>);
+        if (p.lgRW == 5) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 5>) : go(wgrad16_kernel<T, 3, 5>);
+        return p.MC == 6 ? go(wgrad16_kernel<T, 6, 4>) : go(wgrad16_kernel<T, 3, 4>);
     };
     prof_begin(c.kclass, c.flops, s);
     const int rc = dt == SPRK_DT_BF16 ? pick(__bf16{}) : pick(_Float16{});

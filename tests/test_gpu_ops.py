@@ -438,6 +438,8 @@ CONV16_CASES = [
     ("c16 wgrad enc2 plain 48->48 @32", 64, 48, 0, 32, 32, 48, 3, (1, 1, 1, 1), 1, True, False),
     ("c16 wgrad 2 segments 96->96 @128x64", 4, 96, 0, 128, 64, 96, 3, (2, 0, 1, 1), 1, True, False),
     ("c16 wgrad 40+30->88 @64x128 pad(1,1,2,0)", 8, 40, 30, 64, 128, 88, 3, (1, 1, 2, 0), 0, True, False),
+    ("c16 wgrad dec3.0 shift 96+48->96 @16 (8 x 16 regions)", 256, 96, 48, 16, 16, 96, 3, (2, 0, 1, 1), 1, True, False),
+    ("c16 wgrad enc3 plain 48->48 @16", 256, 48, 0, 16, 16, 48, 3, (1, 1, 1, 1), 1, True, False),
     # 1x1 backward-weight kernel: 192 x 192 blocks (Cout > 96), 96 x 384 blocks, ragged channel counts / region split
     ("c16 wgrad 1x1 384->384 @64", 16, 384, 0, 64, 64, 384, 1, (0, 0, 0, 0), 1, True, False),
     ("c16 wgrad 1x1 384->96 @64", 16, 384, 0, 64, 64, 96, 1, (0, 0, 0, 0), 1, True, False),
@@ -520,7 +522,7 @@ def test_conv2d_16bit_operands(case, dt):
     # weight gradient: on the 16-bit backward-weight kernel (wgrad16.hip) when the layer is large enough — then it is
     # conv_weight(round16(x), round16(gpre)) with exact products and fp32 sums (exact model, 1e-4: sums of up to
     # 5e5 fp32 terms over 256 partial results) — otherwise on the fp32 kernels: the unrounded fp64 statement
-    wg16 = (K == 3 and 33 <= Cout <= 96 and (W % 64 == 0 or W == 32) and H % (128 // min(W, 64)) == 0
+    wg16 = (K == 3 and 33 <= Cout <= 96 and (W % 64 == 0 or W in (16, 32)) and H % (128 // min(W, 64)) == 0
             and N * H * W >= 65536 and not up_out)
     wg16 = wg16 or (K == 1 and Cout >= 33 and C1 >= 97 and C2 == 0 and (H * W) % 64 == 0 and N * H * W >= 65536)
     assert L.sprk_wgrad16_launch_count() == w0 + int(wg16), "backward-weight kernel choice"
