@@ -1379,7 +1379,7 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
         const sprk::Conv16Call c16 = call16_fwd(g, ep);
         if (sprk::conv16_eligible(c16)) return sprk::conv16_run(c16, x, x2, w, y, ws, ws_bytes, s);
     }
-    if (sprk::wino_eligible(wino_geom_fwd(g, ep)) && !ep->up2 && !ep->res) {
+    if (sprk::wino_eligible(wino_geom_fwd(g, ep)) && !ep->res) {
         const size_t need = sprk::wino_ws_bytes(g->C1, g->C2, g->Cout);
         if (ws_bytes < need || !ws) {
             sprk::set_error("conv2d_fwd: workspace %zu < %zu", ws_bytes, need);
@@ -1387,7 +1387,7 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
         }
         sprk::WinoArgs wa{x, x2, w, ep->bias, ep->scale, ep->shift, y, (float *)ws, g->N, g->C1, g->C2, g->Hin, g->Win,
                           g->Cout, g->pad_top, g->pad_left, ep->act, 0, g->Cout > 48 ? kClassWino : 2,
-                          2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * 9};
+                          2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * (g->C1 + g->C2) * 9, ep->up2 ? 1 : 0};
         if (int rc = sprk::wino_conv(wa, s)) return rc;
         return sprk::check_launch("wino_conv");
     }

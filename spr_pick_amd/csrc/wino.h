@@ -17,6 +17,7 @@ struct WinoArgs {
     int mode;              // 0: forward taps w[cout][cin]; 1: backward-data taps w[k][cout] flipped
     int kclass;            // profiling class of the main kernel launch (sprk_prof_*)
     double flops;          // algorithmic (direct-convolution) FLOPs of this call, for the same
+    int up2;               // 1: y is [N,Cout,2H,2W], every output written to its 2x2 block (fused nn.Upsample)
 };
 
 struct WinoWgArgs {

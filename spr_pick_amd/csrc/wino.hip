@@ -134,7 +134,7 @@ struct IC {
 struct KArgs {
     const float *x, *x2, *U, *bias, *scale, *shift;
     float *y;
-    int N, C1, C2, H, W, Cout, padT, padL, act, tilesX, tilesY, ntiles, nc1, nch;
+    int N, C1, C2, H, W, Cout, padT, padL, act, tilesX, tilesY, ntiles, nc1, nch, up2;
 };
 
 template <int NT, int SQ>
@@ -338,9 +338,19 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
                     o0 = __builtin_elementwise_max(o0, (f32x2){0.f, 0.f});
                     o1 = __builtin_elementwise_max(o1, (f32x2){0.f, 0.f});
                 }
-                float *yp = a.y + (((long)e_n * a.Cout + co) * a.H + oy) * a.W + ox;
-                *reinterpret_cast<f32x2 *>(yp) = o0;
-                *reinterpret_cast<f32x2 *>(yp + a.W) = o1;
+                if (a.up2) {   // nearest x2 upsampling fused into the stores: each value to its 2x2 block
+                    const int W2 = 2 * a.W;
+                    float *yp = a.y + (((long)e_n * a.Cout + co) * (2 * a.H) + 2 * oy) * W2 + 2 * ox;
+                    const f32x4 r0 = {o0[0], o0[0], o0[1], o0[1]}, r1 = {o1[0], o1[0], o1[1], o1[1]};
+                    *reinterpret_cast<f32x4 *>(yp) = r0;
+                    *reinterpret_cast<f32x4 *>(yp + W2) = r0;
+                    *reinterpret_cast<f32x4 *>(yp + 2 * W2) = r1;
+                    *reinterpret_cast<f32x4 *>(yp + 3 * W2) = r1;
+                } else {
+                    float *yp = a.y + (((long)e_n * a.Cout + co) * a.H + oy) * a.W + ox;
+                    *reinterpret_cast<f32x2 *>(yp) = o0;
+                    *reinterpret_cast<f32x2 *>(yp + a.W) = o1;
+                }
             }
         }
         __syncthreads();
@@ -596,7 +606,7 @@ namespace sprk {
 bool wino_eligible(const WinoGeom &g) {
     static const int on = getenv("SPRK_WINO") ? atoi(getenv("SPRK_WINO")) : 1;   // debug: 0 = direct kernels only
     if (!on) return false;
-    if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.dil != 1 || g.up1 || g.up2 || g.res) return false;
+    if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.dil != 1 || g.up1 || g.res) return false;
     if (g.Hout != g.H || g.Wout != g.W) return false;
     const int sq = wino_square(g.H, g.W);
     if (sq < 0) return false;
@@ -621,6 +631,7 @@ int wino_conv(const WinoArgs &w, hipStream_t s) {
     a.x = w.x; a.x2 = w.x2; a.U = w.U; a.bias = w.bias; a.scale = w.scale; a.shift = w.shift; a.y = w.y;
     a.N = w.N; a.C1 = w.C1; a.C2 = w.C2; a.H = w.H; a.W = w.W; a.Cout = w.Cout; a.padT = w.padT; a.padL = w.padL;
     a.act = w.act;
+    a.up2 = w.up2;
     const int sq = wino_square(w.H, w.W);
     a.tilesX = w.W / (sq ? Geo<1>::TC : Geo<0>::TC); a.tilesY = w.H / (sq ? Geo<1>::TR : Geo<0>::TR);
     a.ntiles = a.tilesX * a.tilesY * w.N;

@@ -181,6 +181,36 @@ def test_conv2d_winograd(case):
         close(dl[3].grad, leaves[3].grad, rel=5e-5, name=name + " gb")
 
 
+@pytest.mark.parametrize("shape", [(64, 96, 0, 32, 32, 96), (192, 96, 48, 16, 16, 96), (12, 48, 0, 64, 64, 48)])
+def test_conv2d_winograd_fused_upsample(shape):
+    """up_out on the Winograd kernel (the decoder's second convolutions write their nearest-x2 upsampled output
+    directly): every value appears in its 2x2 block, values and gradients as conv + nn.Upsample in fp64."""
+    from spr_pick_amd import _lib, ops
+    N, C1, C2, H, W, Cout = shape
+    g = torch.Generator().manual_seed(31 + H)
+    x = torch.randn(N, C1, H, W, generator=g)
+    x2 = torch.randn(N, C2, H, W, generator=g) if C2 else None
+    w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / np.sqrt((C1 + C2) * 9)
+    b = torch.randn(Cout, generator=g) * 0.1
+    pad = (2, 0, 1, 1)
+    d = dev()
+    L = _lib.lib()
+    dl = [t.to(d).requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
+    before = L.sprk_wino_launch_count()
+    y = ops.conv2d(dl[0], dl[2], dl[3], x2=dl[1], pad=pad, act=1, up_out=True)
+    assert L.sprk_wino_launch_count() == before + 1, "up_out forward did not take the Winograd kernel"
+    assert tuple(y.shape) == (N, Cout, 2 * H, 2 * W)
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (x, x2, w, b)]
+    yr = F.interpolate(ref_conv(leaves[0], leaves[1], leaves[2], leaves[3], 0, 1, 1, pad, 1), scale_factor=2, mode="nearest")
+    close(y, yr, name="wino up_out y")
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    y.backward(gy.to(d))
+    close(dl[0].grad, leaves[0].grad, rel=5e-5, name="wino up_out gx")
+    close(dl[2].grad, leaves[2].grad, rel=5e-5, name="wino up_out gw")
+    close(dl[3].grad, leaves[3].grad, rel=5e-5, name="wino up_out gb")
+
+
 def test_conv2d_winograd_affine_epilogue_and_switch():
     """Inference epilogue relu(conv * scale + shift) on the Winograd kernel, and SPRK_WINO-independent
     agreement with the plain direct kernel on the same input (SPRK_DT_NAIVE routes around both)."""
