@@ -68,7 +68,7 @@ def test_torch_library_registration_and_fake_shapes():
     names = set(torch_ops.registered())
     assert {"conv2d_fwd", "conv2d_bwd_data", "conv2d_bwd_weight", "act_bwd", "shift_maxpool2_fwd", "rot4_stack_fwd",
             "unrot4_shift_concat_fwd", "bn_train_fwd", "bn_train_bwd", "bn_eval_fwd", "reparam_fwd", "sigmoid_clamp_fwd",
-            "ssdn_fwd", "ssdn_bwd", "nms2d"} <= names
+            "ssdn_fwd", "ssdn_bwd", "nms2d", "pu_loss", "reduce_pending"} <= names
     for n in names:
         assert hasattr(torch.ops.sprk, n)
     with FakeTensorMode():
@@ -82,6 +82,12 @@ def test_torch_library_registration_and_fake_shapes():
         assert tuple(torch.ops.sprk.shift_maxpool2_fwd(x, 1).shape) == (4, 48, 32, 32)
         assert tuple(torch.ops.sprk.rot4_stack_fwd(torch.empty(2, 1, 8, 8, device="cuda")).shape) == (8, 1, 8, 8)
         assert tuple(torch.ops.sprk.unrot4_shift_concat_fwd(torch.empty(8, 96, 8, 8, device="cuda")).shape) == (2, 384, 8, 8)
+        c = torch.empty(32, device="cuda")
+        yb, mean, invstd = torch.ops.sprk.bn_train_fwd(torch.empty(8, 32, 9, 9, device="cuda"), c, c, c, c, 0.1, 1e-5, True, 2)
+        assert tuple(yb.shape) == (8, 32, 9, 9) and tuple(mean.shape) == (2, 32) == tuple(invstd.shape)   # per-group statistics
+        loss, gp = torch.ops.sprk.pu_loss(torch.empty(16, device="cuda"), torch.empty(16, device="cuda"),
+                                          torch.empty(17, 17, device="cuda"), 4.0)
+        assert tuple(loss.shape) == (1,) and tuple(gp.shape) == (16,)
     # CPU tensors: no CPU kernel is registered, the functional API refuses them up front
     import pytest
     from spr_pick_amd import _lib
