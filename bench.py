@@ -245,7 +245,7 @@ def main():
     torch.manual_seed(1000 + rank)
 
     def step(i, eager=False):
-        """forward + backward (HIP-graph replay unless `eager`) -> in-place flat gradient all-reduce -> fused Adam"""
+        """forward + backward (HIP-graph replay unless `eager`) -> in-place flat gradient all-reduce -> one-launch Adam"""
         inp, tgt = batches[i % nb]
         o = stepper(inp, tgt, eager=eager)
         stepper.grads.all_reduce(world)
@@ -426,7 +426,7 @@ def main():
                    "parallelism": "dp%d (in-place flat fp32 gradient all-reduce over RCCL, %d floats)" % (world, stepper.grads.live_numel)
                                   if world > 1 else "single GPU",
                    "execution": ("forward+backward replayed from 2 HIP graphs (one per flip axis, %d kernels each), eager "
-                                 "all-reduce + fused Adam" % (stepper.kernels_per_step or 0)) if use_graph
+                                 "all-reduce + one-launch Adam (sprk_adam_multi)" % (stepper.kernels_per_step or 0)) if use_graph
                                 else "every launch enqueued from Python (--graph off)"},
         "roofline": {"bound": "mfma", "kernel": nm, "kernel_note": note,
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

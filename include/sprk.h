@@ -208,6 +208,22 @@ int sprk_sigmoid_clamp_bwd(const float *gp, const float *x, float *gx, long n, v
  * p in (0, 1) (sigmoid_clamp output).  One workgroup; sums in a fixed order. */
 int sprk_pu_loss(const float *p, const float *y, const float *log_binom, int B, float slack,
                  float *loss, float *gp, void *stream);
+/* Adam update of many parameter tensors in ONE launch (train.py:128-140: Adam(lr, betas = (0.9, 0.99)), eps 1e-8, no
+ * weight decay, no amsgrad; the formulas of torch.optim.Adam):
+ *   t = step_in[0] + 1;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+ *   p -= lr[0] / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps);   step_out[0] = t
+ * items / start live in DEVICE memory (built once: the addresses of a training run do not change): item i owns
+ * workgroups start[i] .. start[i+1]-1, 1024 elements each.  lr, step_in, step_out: device scalars (step_in != step_out),
+ * so the call can sit in a captured graph and the learning-rate ramp needs no host sync. */
+typedef struct sprk_adam_item {
+    float *p;
+    const float *g;
+    float *m, *v;
+    long n;
+} sprk_adam_item;
+int sprk_adam_multi(const sprk_adam_item *items, const int *start, int n_items, int n_blocks,
+                    const float *lr, const float *step_in, float *step_out,
+                    float beta1, float beta2, float eps, void *stream);
 /* SSDN gaussian likelihood + posterior mean (denoiser_v2.py:449-462, :514):
  *   var_x = A^2, var_n = s^2, var_y = var_x + var_n
  *   nll = (x-mu)^2/var_y + log var_y - 0.05 s      -> loss[b] = mean over HW

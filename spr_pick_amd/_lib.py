@@ -31,6 +31,11 @@ class ConvEpilogue(ctypes.Structure):
                 ("act", ctypes.c_int32), ("up2", ctypes.c_int32)]
 
 
+class AdamItem(ctypes.Structure):
+    """sprk_adam_item (include/sprk.h)."""
+    _fields_ = [("p", c_vp), ("g", c_vp), ("m", c_vp), ("v", c_vp), ("n", ctypes.c_long)]
+
+
 class ReduceItem(ctypes.Structure):
     """sprk_reduce_item: a pending second-stage sum (include/sprk.h)."""
     _fields_ = [("src", c_vp), ("dst", c_vp), ("kind", ctypes.c_int32), ("parts", ctypes.c_int32), ("n", ctypes.c_int32),
@@ -68,6 +73,7 @@ _SIGS = {
     "sprk_bn_train_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "sprk_reparam_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_vp]),
     "sprk_reparam_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_vp]),
+    "sprk_adam_multi": (c_i, [c_vp, c_vp, c_i, c_i, c_f, c_f, c_f, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_vp]),
     "sprk_pu_loss": (c_i, [c_f, c_f, c_f, c_i, ctypes.c_float, c_f, c_f, c_vp]),
     "sprk_sigmoid_clamp_fwd": (c_i, [c_f, c_f, ctypes.c_long, c_vp]),
     "sprk_sigmoid_clamp_bwd": (c_i, [c_f, c_f, c_f, ctypes.c_long, c_vp]),

@@ -416,6 +416,49 @@ __global__ __launch_bounds__(kSsdnBlk) void ssdn_bwd_kernel(const float *__restr
 
 int ssdn_nblk(int HW) { return std::max(1, std::min(64, sprk::cdiv(HW, kSsdnBlk * 4))); }
 
+
+// ---- Adam over many parameter tensors in one launch --------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_multi_kernel(const sprk_adam_item *__restrict__ items,
+                                                         const int *__restrict__ start, int n_items,
+                                                         const float *__restrict__ lr, const float *__restrict__ step_in,
+                                                         float *__restrict__ step_out, float b1, float b2, float eps) {
+    // workgroup -> item: binary search in the start table (wave-uniform)
+    const int b = blockIdx.x;
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (start[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    const sprk_adam_item it = items[lo];
+    const float t = step_in[0] + 1.f;
+    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+    const float step_size = lr[0] / bc1, rs2 = 1.f / sqrtf(bc2);
+    const long e0 = (long)(b - start[lo]) * 1024 + threadIdx.x * 4;
+    if (e0 + 3 < it.n && ((((uintptr_t)it.p | (uintptr_t)it.g | (uintptr_t)it.m | (uintptr_t)it.v) & 15) == 0)) {
+        const float4 g = *reinterpret_cast<const float4 *>(it.g + e0);
+        float4 m = *reinterpret_cast<const float4 *>(it.m + e0), v = *reinterpret_cast<const float4 *>(it.v + e0);
+        float4 p = *reinterpret_cast<const float4 *>(it.p + e0);
+        m.x = b1 * m.x + (1.f - b1) * g.x; m.y = b1 * m.y + (1.f - b1) * g.y;
+        m.z = b1 * m.z + (1.f - b1) * g.z; m.w = b1 * m.w + (1.f - b1) * g.w;
+        v.x = b2 * v.x + (1.f - b2) * g.x * g.x; v.y = b2 * v.y + (1.f - b2) * g.y * g.y;
+        v.z = b2 * v.z + (1.f - b2) * g.z * g.z; v.w = b2 * v.w + (1.f - b2) * g.w * g.w;
+        p.x -= step_size * m.x / (sqrtf(v.x) * rs2 + eps); p.y -= step_size * m.y / (sqrtf(v.y) * rs2 + eps);
+        p.z -= step_size * m.z / (sqrtf(v.z) * rs2 + eps); p.w -= step_size * m.w / (sqrtf(v.w) * rs2 + eps);
+        *reinterpret_cast<float4 *>(it.m + e0) = m;
+        *reinterpret_cast<float4 *>(it.v + e0) = v;
+        *reinterpret_cast<float4 *>(it.p + e0) = p;
+    } else {
+        for (long e = e0; e < it.n && e < e0 + 4; ++e) {
+            const float g = it.g[e];
+            const float m = b1 * it.m[e] + (1.f - b1) * g, v = b2 * it.v[e] + (1.f - b2) * g * g;
+            it.m[e] = m;
+            it.v[e] = v;
+            it.p[e] -= step_size * m / (sqrtf(v) * rs2 + eps);
+        }
+    }
+    if (b == 0 && threadIdx.x == 0) step_out[0] = t;
+}
+
 }  // namespace
 
 extern "C" {
@@ -500,6 +543,15 @@ int sprk_sigmoid_clamp_bwd(const float *gp, const float *x, float *gx, long n, v
     hipLaunchKernelGGL(sigmoid_clamp_bwd_kernel, dim3(sprk::ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, gp, x, gx,
                        n);
     return sprk::check_launch("sigmoid_clamp_bwd");
+}
+
+int sprk_adam_multi(const sprk_adam_item *items, const int *start, int n_items, int n_blocks, const float *lr,
+                    const float *step_in, float *step_out, float beta1, float beta2, float eps, void *stream) {
+    SPRK_REQUIRE(items && start && n_items > 0 && n_blocks > 0 && lr && step_in && step_out && step_in != step_out,
+                 "adam_multi: bad arguments");
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, items, start, n_items, lr,
+                       step_in, step_out, beta1, beta2, eps);
+    return sprk::check_launch("adam_multi");
 }
 
 int sprk_pu_loss(const float *p, const float *y, const float *log_binom, int B, float slack, float *loss, float *gp,

@@ -14,8 +14,9 @@ Gradients are written by the backward kernels straight into slices of ONE flat f
   * the data-parallel all-reduce runs in place on that buffer — no gather / scatter copies around the collective
     (distributed.FlatGradAllReduce copies twice);
   * the 1/world of the gradient average is folded into the loss before backward (exact for world = 2^k).
-The all-reduce and the Adam update stay outside the graphs (eager; Adam is the fused, capturable implementation, a
-handful of launches with the learning rate in a device tensor so the ramp needs no re-capture).
+The all-reduce and the Adam update stay outside the graphs (eager): Adam is ONE launch over all parameter tensors
+(``MultiAdam`` / ``sprk_adam_multi``) with the step count and the learning rate in device scalars, so the ramp
+needs no re-capture and no host sync.
 """
 import numpy as np
 import torch
@@ -126,13 +127,113 @@ class FlatGrads:
         return False
 
 
+class MultiAdam:
+    """Adam as the reference configures it (train.py:128-140: lr, betas (0.9, 0.99), eps 1e-8, no weight decay) with
+    the whole update in ONE launch (``sprk_adam_multi``): torch's fused Adam walks the ~130 parameter tensors in 3
+    launches of 30-50 workgroups (240 us per step, 1-2 % of it); here a device-resident table maps workgroups to
+    parameter tensors (1024 elements each), the moments are two flat buffers and the step count and learning rate are
+    device scalars, so nothing synchronises and the ramped rate is set with ``set_lr``.
+
+    ``state_dict()`` / ``load_state_dict()`` use torch.optim.Adam's layout (per-parameter ``step`` / ``exp_avg`` /
+    ``exp_avg_sq``), so checkpoints written with either load into the other."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.99), eps=1e-8):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("MultiAdam: no parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("MultiAdam runs on the GPU only")
+        self.dev, self.betas, self.eps = dev, (float(betas[0]), float(betas[1])), float(eps)
+        self.lr = torch.tensor(float(lr), dtype=torch.float32, device=dev)
+        self.param_groups = [{"lr": self.lr, "betas": self.betas, "eps": self.eps, "params": self.params}]
+        self._offsets, off = [], 0
+        for p in self.params:
+            self._offsets.append(off)
+            off += (p.numel() + 3) // 4 * 4          # 16-byte aligned slices
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        self._steps = [torch.zeros(1, dtype=torch.float32, device=dev), torch.zeros(1, dtype=torch.float32, device=dev)]
+        self._cur = 0                 # index of the buffer holding the current step count
+        self._started = set()         # indices of the parameters that have taken a step (torch creates state lazily)
+        self._key = None
+        self._table = None
+
+    def _slice(self, buf, i):
+        p = self.params[i]
+        return buf[self._offsets[i]:self._offsets[i] + p.numel()]
+
+    def _build(self, live):
+        items = (_lib.AdamItem * len(live))()
+        start = np.zeros(len(live) + 1, dtype=np.int32)
+        for k, i in enumerate(live):
+            p = self.params[i]
+            if not (p.is_contiguous() and p.grad.is_contiguous() and p.grad.dtype == torch.float32):
+                raise _lib.SprkError("MultiAdam: parameters and gradients must be contiguous fp32")
+            items[k] = _lib.AdamItem(p.data_ptr(), p.grad.data_ptr(), self._slice(self.exp_avg, i).data_ptr(),
+                                     self._slice(self.exp_avg_sq, i).data_ptr(), p.numel())
+            start[k + 1] = start[k] + (p.numel() + 1023) // 1024
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        self._table = (raw.to(self.dev), torch.from_numpy(start).to(self.dev), len(live), int(start[-1]))
+        self._started.update(live)
+
+    def step(self):
+        live = [i for i, p in enumerate(self.params) if p.grad is not None]
+        if not live:
+            return
+        key = tuple((i, self.params[i].data_ptr(), self.params[i].grad.data_ptr()) for i in live)
+        if key != self._key:          # first step, or the gradients moved (not in a FlatGrads run): new table
+            self._build(live)
+            self._key = key
+        items, start, n, blocks = self._table
+        src, dst = self._steps[self._cur], self._steps[1 - self._cur]
+        _lib.check(_lib.lib().sprk_adam_multi(items.data_ptr(), start.data_ptr(), n, blocks, self.lr.data_ptr(), src.data_ptr(),
+                                              dst.data_ptr(), self.betas[0], self.betas[1], self.eps,
+                                              torch.cuda.current_stream(self.dev).cuda_stream), "sprk_adam_multi")
+        self._cur = 1 - self._cur
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def state_dict(self):
+        step = self._steps[self._cur].clone().reshape(())
+        state = {i: {"step": step.clone(), "exp_avg": self._slice(self.exp_avg, i).clone().view(self.params[i].shape),
+                     "exp_avg_sq": self._slice(self.exp_avg_sq, i).clone().view(self.params[i].shape)}
+                 for i in sorted(self._started)}
+        return {"state": state, "param_groups": [{"lr": float(self.lr), "betas": self.betas, "eps": self.eps,
+                                                  "weight_decay": 0, "amsgrad": False,
+                                                  "params": list(range(len(self.params)))}]}
+
+    def load_state_dict(self, sd):
+        groups = sd.get("param_groups", [])
+        if sum(len(g["params"]) for g in groups) != len(self.params):
+            raise ValueError("MultiAdam: the checkpoint's optimiser has a different number of parameters")
+        steps = set()
+        self._started = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, st in sd["state"].items():
+            i = int(i)
+            if tuple(st["exp_avg"].shape) != tuple(self.params[i].shape):
+                raise ValueError("MultiAdam: moment shape mismatch for parameter %d" % i)
+            self._slice(self.exp_avg, i).copy_(st["exp_avg"].reshape(-1))
+            self._slice(self.exp_avg_sq, i).copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(float(st["step"]))
+            self._started.add(i)
+        if len(steps) > 1:
+            raise ValueError("MultiAdam: parameters with different step counts (%s)" % sorted(steps))
+        self._steps[self._cur].fill_(steps.pop() if steps else 0.0)
+        self._key = None
+
+
 def make_adam(params, lr=1e-4, betas=(0.9, 0.99)):
-    """Adam as the reference configures it (train.py:128-140), in the fused + capturable form: state and learning
-    rate live on the device, so a step never synchronises and the ramped rate is set with ``set_lr``."""
-    params = list(params)
-    dev = params[0].device
-    return torch.optim.Adam(params, lr=torch.tensor(float(lr), dtype=torch.float32, device=dev), betas=betas,
-                            capturable=True, fused=True)
+    """Adam as the reference configures it (train.py:128-140): one launch per step, state and learning rate on the
+    device (``MultiAdam``)."""
+    return MultiAdam(list(params), lr=lr, betas=betas)
 
 
 def set_lr(optimizer, lr):
