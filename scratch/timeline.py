@@ -21,12 +21,13 @@ def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n)
     return re.sub(r"\(.*$", "", n)[:70]
 # step boundaries: the fused Adam kernels end a step
-adam = [i for i, r in enumerate(rows) if "FusedAdam" in r[0]]
+adam = [i for i, r in enumerate(rows) if "FusedAdam" in r[0] or "adam_multi" in r[0]]
 ends = [i for j, i in enumerate(adam) if j + 1 == len(adam) or adam[j + 1] - i > 20]
+segs_min = 150
 if len(ends) < 3:
     print("cannot find steps"); sys.exit(1)
 segs = [(ends[i] + 1, ends[i + 1] + 1) for i in range(len(ends) - 1)]
-segs = [sg for sg in segs if sg[1] - sg[0] > 200]
+segs = [sg for sg in segs if sg[1] - sg[0] > segs_min]
 lo, hi = min(segs, key=lambda sg: rows[sg[1] - 1][2] - rows[sg[0]][1])      # the fastest step = a graph replay
 print("# steps found: %d, walls ms: %s" % (len(segs), " ".join("%.2f" % ((rows[b - 1][2] - rows[a][1]) / 1e6) for a, b in segs)))
 step = rows[lo:hi]

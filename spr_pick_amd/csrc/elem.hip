@@ -3,6 +3,8 @@
 // (coalesced along x); none of them is reshaped into a GEMM.
 #include "common.h"
 
+#include <algorithm>
+
 namespace {
 
 // ---- Shift2d((shift,0)) + MaxPool2d(2) -------------------------------------------------------
@@ -63,6 +65,47 @@ __global__ void shift_maxpool2_bwd_kernel(const float *__restrict__ gy, const fl
             if (best == mine) g = gy[(nc * Ho + i) * Wo + j];
         }
         gx[e] = g;
+    }
+}
+
+// the same rule with four x elements of one row per thread (W % 4 == 0, H even, 16-byte aligned planes): two
+// windows; the thread loads its own row and the partner row of the window pair (float4 each, the partner's from
+// cache), the two gradients (float2) and writes one float4 — no 64-bit index division, 16-byte accesses
+__device__ __forceinline__ int first_max4(float a, float b, float c, float d) {
+    int best = 0;
+    float m = a;
+    if (b > m || b != b) m = b, best = 1;
+    if (c > m || c != c) m = c, best = 2;
+    if (d > m || d != d) m = d, best = 3;
+    return best;
+}
+
+__global__ __launch_bounds__(256) void shift_maxpool2_bwd_v4_kernel(const float *__restrict__ gy,
+                                                                    const float *__restrict__ x, float *__restrict__ gx,
+                                                                    int NC, int H, int W, int shift) {
+    const int Ho = H >> 1, Wo = W >> 1, W4 = W >> 2;
+    const int per = H * W4;
+    for (int nc = blockIdx.y; nc < NC; nc += gridDim.y) {
+        const float *p = x + (long)nc * H * W;
+        for (int t = blockIdx.x * 256 + threadIdx.x; t < per; t += gridDim.x * 256) {
+            const int r0 = t / W4, q = t - r0 * W4;
+            const int u = r0 + shift;               // row in the shifted image
+            float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < 2 * Ho) {
+                const int i = u >> 1, ra = (u & ~1) - shift, rb = ra + 1;   // x rows of the window (ra < 0: zeros)
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 A = ra >= 0 ? *reinterpret_cast<const float4 *>(p + (long)ra * W + 4 * q) : z;
+                const float4 B = rb >= 0 ? *reinterpret_cast<const float4 *>(p + (long)rb * W + 4 * q) : z;
+                const float2 g = *reinterpret_cast<const float2 *>(gy + ((long)nc * Ho + i) * Wo + 2 * q);
+                const int b0 = first_max4(A.x, A.y, B.x, B.y), b1 = first_max4(A.z, A.w, B.z, B.w);
+                const int k0 = (u & 1) << 1;        // window positions of this thread's row: k0, k0 + 1
+                out.x = b0 == k0 ? g.x : 0.f;
+                out.y = b0 == k0 + 1 ? g.x : 0.f;
+                out.z = b1 == k0 ? g.y : 0.f;
+                out.w = b1 == k0 + 1 ? g.y : 0.f;
+            }
+            *reinterpret_cast<float4 *>(gx + (long)nc * H * W + (long)r0 * W + 4 * q) = out;
+        }
     }
 }
 
@@ -474,6 +517,12 @@ int sprk_shift_maxpool2_fwd(const float *x, float *y, int NC, int H, int W, int 
 int sprk_shift_maxpool2_bwd(const float *gy, const float *x, float *gx, int NC, int H, int W, int shift, void *stream) {
     SPRK_REQUIRE(gy && x && gx && NC > 0 && H >= 2 && W >= 2 && shift >= 0, "shift_maxpool2_bwd: bad arguments");
     const long total = (long)NC * H * W;
+    if (W % 4 == 0 && H % 2 == 0 && ((((uintptr_t)x | (uintptr_t)gx) & 15) == 0) && (((uintptr_t)gy & 7) == 0)) {
+        const int per = H * (W / 4);
+        dim3 grid(std::min(sprk::cdiv(per, 256), 64), std::min(NC, 32768));
+        hipLaunchKernelGGL(shift_maxpool2_bwd_v4_kernel, grid, dim3(256), 0, (hipStream_t)stream, gy, x, gx, NC, H, W, shift);
+        return sprk::check_launch("shift_maxpool2_bwd_v4");
+    }
     hipLaunchKernelGGL(shift_maxpool2_bwd_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, gy,
                        x, gx, NC, H, W, shift);
     return sprk::check_launch("shift_maxpool2_bwd");

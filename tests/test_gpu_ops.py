@@ -295,6 +295,24 @@ def test_shift_maxpool(shape, shift):
     assert torch.equal(xd.grad.cpu(), xr.grad.float())
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 12, 4), (3, 48, 64, 64), (1, 2, 6, 10)])
+def test_shift_maxpool_ties_go_to_the_first_maximum(shape):
+    """Few distinct values: most windows have tied maxima; the gradient goes to the first one in row-major order
+    (torch's rule), in the vectorised backward kernel (W % 4 == 0) and in the general one."""
+    from spr_pick_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randint(0, 3, shape, generator=g).float()
+    xr = x.double().requires_grad_(True)
+    yr = F.max_pool2d(F.pad(xr, (0, 0, 1, 0))[:, :, : shape[2]], 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+    xd = x.to(dev()).requires_grad_(True)
+    y = ops.shift_maxpool2(xd, 1)
+    assert torch.equal(y.cpu(), yr.float())
+    y.backward(gy.to(dev()))
+    assert torch.equal(xd.grad.cpu(), xr.grad.float())
+
+
 @pytest.mark.parametrize("B,C,P", [(2, 1, 64), (3, 2, 8), (1, 4, 2), (2, 3, 96)])
 def test_rot4_and_unrot4(B, C, P):
     from oracle import networks
