@@ -160,10 +160,11 @@ class _Conv2dFn(torch.autograd.Function):
                               g.pad_top, g.pad_left, g.dtype)
                 wd = w[:, :g.C1].contiguous()
             gsrc = gpre
-            if gd.stride > 1 and not (gd.dtype & _lib.DT_NAIVE):
+            if gd.stride > 1 and gd.C1 + gd.C2 >= 16 and not (gd.dtype & _lib.DT_NAIVE):
                 # strided layers (the detector's down-sampling convolutions): the gradient w.r.t. the input is the
                 # stride-1 backward-data of gy with stride - 1 zeros between its samples — the MFMA kernel on a
-                # zero-stuffed copy (tiny tensors) instead of the direct kernel
+                # zero-stuffed copy (tiny tensors) instead of the direct kernel (which stays for the 7x7 stem: one
+                # input channel would leave 15 of 16 MFMA columns empty)
                 st = gd.stride
                 H1, W1 = (gd.Hout - 1) * st + 1, (gd.Wout - 1) * st + 1
                 gsrc = gpre.new_zeros((gd.N, gd.Cout, H1, W1))
