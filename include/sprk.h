@@ -119,8 +119,12 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
  * [N,C,2H,2W] tensors of a conv with the fused-upsample epilogue; gy is first summed over each
  * 2x2 block (backward of nn.Upsample).  ws: C*nsplit floats. */
 size_t sprk_act_bwd_ws_bytes(int N, int C, int HW);
+/* g_image_stride: elements between consecutive images of gy, 0 = dense (C*H*W, or 4*C*H*W with up2).  A larger
+ * stride reads gy out of a channel slice of a wider tensor (the two halves of a concat layer's input gradient are
+ * handed on as views); y and gpre are always dense. */
 int sprk_act_bwd(const float *gy, const float *y, float *gpre, float *gbias, int act,
-                 int N, int C, int H, int W, int up2, void *ws, size_t ws_bytes, void *stream);
+                 int N, int C, int H, int W, int up2, long g_image_stride,
+                 void *ws, size_t ws_bytes, void *stream);
 /* ---- deferred second-stage reductions ------------------------------------------------------
  * Backward-weight and the bias gradient are two-stage sums: the main kernel leaves per-workgroup partial sums in
  * ws and a small second kernel adds them in a fixed order.  A training step runs ~80 of those second kernels
@@ -142,8 +146,8 @@ int sprk_conv2d_bwd_weight_partial(const float *x, const float *x2, const float 
                                    const sprk_conv_geom *g, void *ws, size_t ws_bytes,
                                    sprk_reduce_item *item, void *stream);
 int sprk_act_bwd_partial(const float *gy, const float *y, float *gpre, float *gbias, int act,
-                         int N, int C, int H, int W, int up2, void *ws, size_t ws_bytes,
-                         sprk_reduce_item *item, void *stream);
+                         int N, int C, int H, int W, int up2, long g_image_stride,
+                         void *ws, size_t ws_bytes, sprk_reduce_item *item, void *stream);
 /* every sum: four interleaved chains over p (p mod 4), combined as (s0 + s1) + (s2 + s3) */
 int sprk_reduce_items(const sprk_reduce_item *items, int n, void *stream);
 

@@ -56,10 +56,10 @@ _SIGS = {
     "sprk_conv2d_bwd_weight_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_bwd_weight": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_weight_partial": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, ctypes.POINTER(ReduceItem), c_vp]),
-    "sprk_act_bwd_partial": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, ctypes.POINTER(ReduceItem), c_vp]),
+    "sprk_act_bwd_partial": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_long, c_vp, c_sz, ctypes.POINTER(ReduceItem), c_vp]),
     "sprk_reduce_items": (c_i, [ctypes.POINTER(ReduceItem), c_i, c_vp]),
     "sprk_act_bwd_ws_bytes": (c_sz, [c_i, c_i, c_i]),
-    "sprk_act_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "sprk_act_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_long, c_vp, c_sz, c_vp]),
     "sprk_concat_up_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "sprk_shift_maxpool2_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),
     "sprk_shift_maxpool2_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),

@@ -841,19 +841,22 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_direct_kernel(const Direc
 // grid (C, nsplit): block (c, s) walks images n = s, s+nsplit, ... of channel c.
 // up2: g and y are the 2x upsampled tensors [N,C,2H,2W] written by a conv with the fused upsample
 // epilogue; the incoming gradient is first summed over each 2x2 block (backward of nn.Upsample).
+// gstride: elements between consecutive images of g (a channel slice of a wider tensor: the backward-data output of
+// a concat layer is handed on as views, not copied); y and gpre are dense.
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const float *__restrict__ y, float *gpre,
                                                       float *__restrict__ partial, int act, int N, int C, int HW,
-                                                      int W, int up2, int nsplit) {
+                                                      int W, int up2, int nsplit, long gstride) {
     const int c = blockIdx.x, s = blockIdx.y;
     float sum = 0.f;
-    const bool al16 = (((uintptr_t)g | (uintptr_t)y | (uintptr_t)gpre) & 15) == 0;
+    const bool al16 = (((uintptr_t)g | (uintptr_t)y | (uintptr_t)gpre) & 15) == 0 && (gstride & 3) == 0;
     const bool v4 = !up2 && (HW & 3) == 0 && al16;
     const bool v2u = up2 && (W & 1) == 0 && al16;
     for (int n = s; n < N; n += nsplit) {
         const long base = ((long)n * C + c) * HW;
+        const long gbase = (long)n * gstride + (long)c * (up2 ? 4L * HW : HW);     // first element of g's plane
         if (v4) {  // 16 bytes per lane
             for (int i = threadIdx.x * 4; i < HW; i += 1024) {
-                float4 v = *reinterpret_cast<const float4 *>(g + base + i);
+                float4 v = *reinterpret_cast<const float4 *>(g + gbase + i);
                 if (act != SPRK_ACT_NONE) {
                     const float4 yv = *reinterpret_cast<const float4 *>(y + base + i);
                     const bool lk = act == SPRK_ACT_LEAKY;
@@ -871,8 +874,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const floa
             for (int i = threadIdx.x * 2; i < HW; i += 512) {
                 const int oy = i / W, ox = i - oy * W;
                 const long q = base * 4 + (long)(2 * oy) * (2 * W) + 2 * ox;
-                const float4 a = *reinterpret_cast<const float4 *>(g + q);
-                const float4 b = *reinterpret_cast<const float4 *>(g + q + 2 * W);
+                const long gq = gbase + (long)(2 * oy) * (2 * W) + 2 * ox;
+                const float4 a = *reinterpret_cast<const float4 *>(g + gq);
+                const float4 b = *reinterpret_cast<const float4 *>(g + gq + 2 * W);
                 float2 v = make_float2((a.x + a.y) + (b.x + b.y), (a.z + a.w) + (b.z + b.w));
                 if (act != SPRK_ACT_NONE) {
                     const float4 yv = *reinterpret_cast<const float4 *>(y + q);
@@ -890,10 +894,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const floa
             if (up2) {
                 const int oy = i / W, ox = i - oy * W;
                 const long q = base * 4 + (long)(2 * oy) * (2 * W) + 2 * ox;
-                v = (g[q] + g[q + 1]) + (g[q + 2 * W] + g[q + 2 * W + 1]);
+                const long gq = gbase + (long)(2 * oy) * (2 * W) + 2 * ox;
+                v = (g[gq] + g[gq + 1]) + (g[gq + 2 * W] + g[gq + 2 * W + 1]);
                 if (act != SPRK_ACT_NONE) yv = y[q];
             } else {
-                v = g[base + i];
+                v = g[gbase + i];
                 if (act != SPRK_ACT_NONE) yv = y[base + i];
             }
             if (act == SPRK_ACT_LEAKY)
@@ -1611,12 +1616,12 @@ size_t sprk_act_bwd_ws_bytes(int N, int C, int HW) {
 }
 
 int sprk_act_bwd(const float *g, const float *y, float *gpre, float *gbias, int act, int N, int C, int H, int W,
-                 int up2, void *ws, size_t ws_bytes, void *stream) {
-    return sprk_act_bwd_partial(g, y, gpre, gbias, act, N, C, H, W, up2, ws, ws_bytes, nullptr, stream);
+                 int up2, long g_image_stride, void *ws, size_t ws_bytes, void *stream) {
+    return sprk_act_bwd_partial(g, y, gpre, gbias, act, N, C, H, W, up2, g_image_stride, ws, ws_bytes, nullptr, stream);
 }
 
 int sprk_act_bwd_partial(const float *g, const float *y, float *gpre, float *gbias, int act, int N, int C, int H, int W,
-                         int up2, void *ws, size_t ws_bytes, sprk_reduce_item *item, void *stream) {
+                         int up2, long g_image_stride, void *ws, size_t ws_bytes, sprk_reduce_item *item, void *stream) {
     if (item) *item = sprk_reduce_item{nullptr, nullptr, SPRK_RED_NONE, 0, 0, 0, 0, 0};
     SPRK_REQUIRE(g && N > 0 && C > 0 && H > 0 && W > 0, "act_bwd: bad arguments");
     SPRK_REQUIRE(act == SPRK_ACT_NONE || (y && gpre), "act_bwd: activation needs the saved output and gpre");
@@ -1628,8 +1633,12 @@ int sprk_act_bwd_partial(const float *g, const float *y, float *gpre, float *gbi
         sprk::set_error("act_bwd: workspace too small");
         return SPRK_EWORKSPACE;
     }
+    const long dense = (long)C * H * W * (up2 ? 4 : 1);
+    const long gs = g_image_stride ? g_image_stride : dense;
+    SPRK_REQUIRE(gs >= dense, "act_bwd: image stride of gy smaller than one image");
+    SPRK_REQUIRE(gs == dense || (gpre && gpre != g), "act_bwd: a strided gy needs a separate gpre");
     hipLaunchKernelGGL(act_bwd_kernel, dim3(C, ns), dim3(256), 0, s, g, y, gpre, gbias ? (float *)ws : nullptr, act, N, C,
-                       H * W, W, up2, ns);
+                       H * W, W, up2, ns, gs);
     if (int rc = sprk::check_launch("act_bwd")) return rc;
     if (gbias) {
         const sprk_reduce_item it{(const float *)ws, gbias, SPRK_RED_COLS, ns, C, 0, 0, 0};

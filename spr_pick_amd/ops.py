@@ -131,8 +131,11 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, x2, w, y, bias = ctx.saved_tensors
         g = ctx.geom
-        gy = gy.contiguous()
         _need_gpu(gy)
+        # a gradient that is a channel slice of a concat layer's input gradient (dense planes, strided images) is read
+        # in place by act_bwd; everything else wants it dense
+        if not (ctx.act != ACT_NONE or ctx.up_out):
+            gy = gy.contiguous()
         gx = gx2 = gw = gb = None
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
         # gradient w.r.t. the pre-activation output (+ bias gradient)
@@ -174,6 +177,10 @@ class _Conv2dFn(torch.autograd.Function):
             gin = _S.conv2d_bwd_data(gsrc, wd, geom_list(gd))
             if gd.C2 == 0 and not gd.up1:
                 gx = gin
+            elif not gd.up1:
+                # concat without upsampling on load: the two halves are handed on as views of gin (their consumers —
+                # act_bwd of the producing layers, autograd's accumulation — read strided images in place)
+                gx, gx2 = gin[:, :gd.C1], gin[:, gd.C1:]
             else:
                 gx, gx2 = _S.concat_up_bwd(gin, gd.C1, gd.C2, gd.up1, list(x.shape), list(x2.shape) if gd.C2 else [0])
                 if not gd.C2:

@@ -151,15 +151,23 @@ def _act_bwd(gy, y, act, geom4, up2, want_gpre, gbias, defer):
     L = _lib.lib()
     N, C, H, W = geom4
     gpre = _f32(gy, (N, C, H, W)) if want_gpre else None
+    # gy may be a channel slice of a wider tensor (dense planes, a larger stride between images): read in place
+    gstride = 0
+    if not gy.is_contiguous():
+        if want_gpre and gy.dim() == 4 and gy[0].is_contiguous() and gy.stride(0) >= gy[0].numel():
+            gstride = gy.stride(0)
+        else:
+            gy = gy.contiguous()
     nb = L.sprk_act_bwd_ws_bytes(N, C, H * W)
     ws = _ws(nb, gy)
     if defer and gbias is not None:
         item = _lib.ReduceItem()
-        check(L.sprk_act_bwd_partial(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, _p(ws), nb, ctypes.byref(item),
-                                     _stream(gy)), "sprk_act_bwd_partial")
+        check(L.sprk_act_bwd_partial(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, gstride, _p(ws), nb,
+                                     ctypes.byref(item), _stream(gy)), "sprk_act_bwd_partial")
         _pend(gy.device, item, ws)
     else:
-        check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, _p(ws), nb, _stream(gy)), "sprk_act_bwd")
+        check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, gstride, _p(ws), nb, _stream(gy)),
+              "sprk_act_bwd")
     return gpre if want_gpre else gy.new_empty(0)
 
 

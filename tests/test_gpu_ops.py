@@ -722,3 +722,44 @@ def test_pu_loss_kernel_every_label_mix():
             close(pd.grad, 1.5 * pr.grad.float(), rel=2e-4, name="pu grad %s %s %s" % (B, labels, tau))
     with pytest.raises(Exception):
         pu(0.01, torch.rand(4), torch.zeros(4))       # CPU tensors: the product path is the GPU kernel
+
+
+@pytest.mark.parametrize("up_out", [False, True])
+def test_concat_halves_are_views_and_act_bwd_reads_them_strided(up_out):
+    """The input gradient of a concat layer is handed on as two channel-slice VIEWS (no copy kernel); the producing
+    layers' act_bwd reads such a gradient in place (dense planes, strided images), also in its 2x2-summing form."""
+    from spr_pick_amd import ops
+    g = torch.Generator().manual_seed(41)
+    d = dev()
+    N, H, W = 6, 16, 32
+    a = torch.randn(N, 5, H, W, generator=g)
+    b = torch.randn(N, 7, 2 * H, 2 * W, generator=g)
+    w1 = torch.randn(24, 5, 3, 3, generator=g) * 0.2
+    w2 = torch.randn(9, 7, 3, 3, generator=g) * 0.2
+    w3 = torch.randn(16, 33, 3, 3, generator=g) * 0.1
+    b1, b2, b3 = torch.randn(24, generator=g), torch.randn(9, generator=g), torch.randn(16, generator=g)
+    if not up_out:
+        a = torch.randn(N, 5, 2 * H, 2 * W, generator=g)
+
+    def ref():
+        t = [x.double().requires_grad_(True) for x in (w1, b1, w2, b2, w3, b3)]
+        y1 = F.leaky_relu(F.conv2d(a.double(), t[0], t[1], padding=1), 0.1)
+        if up_out:
+            y1 = F.interpolate(y1, scale_factor=2, mode="nearest")
+        y2 = F.relu(F.conv2d(b.double(), t[2], t[3], padding=1))
+        z = F.leaky_relu(F.conv2d(torch.cat((y1, y2), 1), t[4], t[5], padding=1), 0.1)
+        (z * z).sum().backward()
+        return [x.grad for x in t]
+
+    t = [x.to(d).requires_grad_(True) for x in (w1, b1, w2, b2, w3, b3)]
+    y1 = ops.conv2d(a.to(d), t[0], t[1], pad=(1, 1, 1, 1), act=1, up_out=up_out)
+    y2 = ops.conv2d(b.to(d), t[2], t[3], pad=(1, 1, 1, 1), act=2)
+    seen = []
+    y1.register_hook(lambda gr: seen.append(("y1", gr.is_contiguous(), gr.stride(0))))
+    y2.register_hook(lambda gr: seen.append(("y2", gr.is_contiguous(), gr.stride(0))))
+    z = ops.conv2d(y1, t[4], t[5], x2=y2, pad=(1, 1, 1, 1), act=1)
+    (z * z).sum().backward()
+    plane = 4 * H * W
+    assert sorted(seen) == [("y1", False, 33 * plane), ("y2", False, 33 * plane)], seen     # views of the 33-channel gin
+    for got, want, name in zip([x.grad for x in t], ref(), ("w1", "b1", "w2", "b2", "w3", "b3")):
+        close(got, want, rel=5e-5, name="strided gy " + name)
