@@ -69,6 +69,12 @@ typedef struct sprk_conv_geom {
 /* or-ed into dtype: run this call on the plain per-output-element kernels (no MFMA, no Winograd): the on-device
  * cross-check the parity tests use.  Per call — the library keeps no mode switch. */
 #define SPRK_DT_NAIVE 0x200
+/* or-ed into dtype: PIN the algorithm to the layer's structure — the choice between the Winograd and the direct kernel
+ * (whose fp32 results differ in the last bits) then depends only on kernel size, channel counts and the divisibility
+ * of the plane (H % 8, W % 32 | H % 16, W % 16), never on how many images or workgroups the call has.  Whole-image and
+ * halo-tiled inference set it, so that a window of a micrograph is computed by exactly the arithmetic the whole
+ * micrograph gets (bit-identical score maps, hence identical picks; tests/test_gpu_pipeline.py). */
+#define SPRK_DT_PIN 0x400
 
 /* Optional fused epilogue of sprk_conv2d_fwd, applied in this order:
  *   v = acc (+ res[n,co,oy+res_off,ox+res_off])            res: [N,Cout,res_h,res_w]
@@ -85,8 +91,15 @@ typedef struct sprk_conv_epilogue {
     int32_t up2;
 } sprk_conv_epilogue;
 
+/* ABI version: bumped whenever a signature or a struct of this header changes incompatibly (100 = round 1; 300: the
+ * geometry carries `dtype`, sprk_act_bwd / sprk_bn_* take the stride / group arguments, the head and prepared-weight
+ * entry points exist).  A binding must refuse a library whose sprk_version() differs from the header it was
+ * written against, and may compare sprk_struct_bytes(0 | 1 | 2) with its own sizeof(sprk_conv_geom |
+ * sprk_conv_epilogue | sprk_reduce_item). */
+#define SPRK_ABI_VERSION 300
 const char *sprk_last_error(void);
 int sprk_version(void);
+size_t sprk_struct_bytes(int which);
 /* number of HIP kernel launches issued by this library since load (diagnostics) */
 long sprk_launch_count(void);
 /* number of convolutions (forward or backward-data) that took the Winograd F(2x2,3x3) kernel (diagnostics) */

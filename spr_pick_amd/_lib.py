@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, "libsprk.so")
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2          # SPRK_DT_*: precision of the MFMA operands (include/sprk.h)
 DT_NAIVE = 0x200                           # SPRK_DT_NAIVE: plain per-output-element kernels for this call (cross-check)
+DT_PIN = 0x400                             # SPRK_DT_PIN: kernel choice by layer structure only (inference: tiled == whole)
 DT_FORCE = 0x100                           # SPRK_DT_FORCE: 16-bit kernel wherever it exists (tests), not only where faster
 DTYPES = {"f32": DT_F32, "fp32": DT_F32, "bf16": DT_BF16, "f16": DT_F16, "fp16": DT_F16,
           "bf16!": DT_BF16 | DT_FORCE, "f16!": DT_F16 | DT_FORCE}
@@ -45,6 +46,7 @@ class ReduceItem(ctypes.Structure):
 _SIGS = {
     "sprk_last_error": (ctypes.c_char_p, []),
     "sprk_version": (c_i, []),
+    "sprk_struct_bytes": (c_sz, [c_i]),
     "sprk_launch_count": (ctypes.c_long, []),
     "sprk_wino_launch_count": (ctypes.c_long, []),
     "sprk_conv16_launch_count": (ctypes.c_long, []),
@@ -88,6 +90,7 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS)
+ABI_VERSION = 300          # SPRK_ABI_VERSION of the include/sprk.h these signatures were written against
 _lib = None
 
 
@@ -107,6 +110,14 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        # a stale library (or a newer one) would read past the geometry struct or misplace arguments silently
+        if L.sprk_version() != ABI_VERSION:
+            raise SprkError("libsprk.so at %s has ABI version %d, this binding needs %d — rebuild it "
+                            "(make -C spr_pick_amd/csrc)" % (LIB_PATH, L.sprk_version(), ABI_VERSION))
+        for which, st in enumerate((ConvGeom, ConvEpilogue, ReduceItem, AdamItem)):
+            if L.sprk_struct_bytes(which) != ctypes.sizeof(st):
+                raise SprkError("libsprk.so: sizeof(%s) is %d in the library, %d in the binding"
+                                % (st.__name__, L.sprk_struct_bytes(which), ctypes.sizeof(st)))
         _lib = L
     return _lib
 

@@ -1295,11 +1295,11 @@ int launch_wg(const WgArgs &a, const WgPlan &p, dim3 grid, hipStream_t s) {
 // Winograd path (wino.hip): geometry of the forward layer / of its backward-data correlation
 sprk::WinoGeom wino_geom_fwd(const sprk_conv_geom *g, const sprk_conv_epilogue *ep) {
     return sprk::WinoGeom{g->N, g->C1, g->C2, g->Cout, g->Hin, g->Win, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil,
-                          g->pad_top, g->pad_left, g->up1, ep ? ep->up2 : 0, (ep && ep->res) ? 1 : 0};
+                          g->pad_top, g->pad_left, g->up1, ep ? ep->up2 : 0, (ep && ep->res) ? 1 : 0, (g->dtype & SPRK_DT_PIN) ? 1 : 0};
 }
 sprk::WinoGeom wino_geom_bwd(const sprk_conv_geom *g) {
     return sprk::WinoGeom{g->N, g->Cout, 0, g->C1 + g->C2, g->Hout, g->Wout, g->Hin, g->Win, g->KH, g->KW, g->stride, g->dil,
-                          (g->KH - 1) * g->dil - g->pad_top, (g->KW - 1) * g->dil - g->pad_left, g->up1, 0, 0};
+                          (g->KH - 1) * g->dil - g->pad_top, (g->KW - 1) * g->dil - g->pad_left, g->up1, 0, 0, (g->dtype & SPRK_DT_PIN) ? 1 : 0};
 }
 // the 16-bit-operand kernels' view of a forward call / of a backward-data call (a forward-shaped convolution of gy
 // with the flipped, channel-transposed taps and mirrored padding)
@@ -1361,7 +1361,14 @@ size_t sprk_conv2d_fwd_ws_bytes(const sprk_conv_geom *g) {
     if (!plan_fwd(g->N, g->C1 + g->C2, g->Cout, g->Hout, g->Wout, g->KH, g->KW, g->stride, g->dil, g->pad_left, g->up1,
                   g->C2 > 0, g->Win, &p)) return 0;
     size_t need = std::max(p.wsBytes, wino_ws_fwd(g));
-    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32) need = std::max(need, sprk::conv16_ws_bytes(call16_fwd(g, nullptr)));
+    if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32) {
+        // the query does not know the epilogue the call will carry: the maximum over the 16-bit plans it can select
+        // (fused up-sampling and a residual exclude some kernels, and the remaining one may need more)
+        for (int v = 0; v < 4; ++v) {
+            sprk_conv_epilogue e = {nullptr, nullptr, nullptr, (v & 2) ? (const float *)g : nullptr, 0, 0, 0, SPRK_ACT_NONE, v & 1};
+            need = std::max(need, sprk::conv16_ws_bytes(call16_fwd(g, &e)));
+        }
+    }
     return need;
 }
 

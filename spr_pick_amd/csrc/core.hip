@@ -154,7 +154,16 @@ int sprk_reduce_items(const sprk_reduce_item *items, int n, void *stream) {
 }
 
 const char *sprk_last_error(void) { return sprk::t_error; }
-int sprk_version(void) { return 100; }
+int sprk_version(void) { return SPRK_ABI_VERSION; }
+size_t sprk_struct_bytes(int which) {
+    switch (which) {
+    case 0: return sizeof(sprk_conv_geom);
+    case 1: return sizeof(sprk_conv_epilogue);
+    case 2: return sizeof(sprk_reduce_item);
+    case 3: return sizeof(sprk_adam_item);
+    default: return 0;
+    }
+}
 long sprk_launch_count(void) { return sprk::g_launches.load(); }
 long sprk_wino_launch_count(void) { return sprk::g_wino_launches.load(); }
 long sprk_conv16_launch_count(void) { return sprk::conv16_launches() + sprk::wgrad16_launches(); }

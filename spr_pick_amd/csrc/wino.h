@@ -6,6 +6,7 @@ namespace sprk {
 
 struct WinoGeom {
     int N, C1, C2, Cout, H, W, Hout, Wout, KH, KW, stride, dil, padT, padL, up1, up2, res;
+    int pin;   // SPRK_DT_PIN: the choice must not depend on the image count or the plane size
 };
 struct WinoArgs {
     const float *x, *x2;   // sources [N,C1,H,W], [N,C2,H,W] (x2 may be null)

@@ -615,7 +615,7 @@ bool wino_eligible(const WinoGeom &g) {
     if (g.C1 < 1 || g.C2 < 0 || g.Cout < 33) return false;
     const int NT = nt_of(g.Cout), groups = cdiv(g.Cout, NT * 16);
     if ((double)g.Cout / (groups * NT * 16) < 0.7) return false;   // padded output channels are wasted MFMAs
-    if ((long)g.N * (g.H / TR) * (g.W / TC) * groups < 192) return false;   // too few workgroups for 256 CUs
+    if (!g.pin && (long)g.N * (g.H / TR) * (g.W / TC) * groups < 192) return false;   // too few workgroups for 256 CUs
     if ((long)4 * g.H * g.W * 4 >= 0x7FFFFFFFL) return false;               // 4 planes inside one buffer range
     return true;
 }

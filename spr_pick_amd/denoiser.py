@@ -91,6 +91,7 @@ class Denoiser(nn.Module):
     SIGMA_ESTIMATOR = "sigma_estimation_model"
     ESTIMATED_SIGMA = "estimated_sigma"
     PROB_ESTIMATOR = "detector_model"
+    MIN_HALO = 352        # receptive field of blind-spot U-Net + filled detector, rounded up to 32 (_tiled_networks)
 
     def __init__(self, cfg, device=None, mode=None):
         super().__init__()
@@ -188,16 +189,28 @@ class Denoiser(nn.Module):
         """Halo-tiled evaluation of the two networks of the filled pipeline: the micrograph is cut
         into interior blocks of ``tile`` pixels, each evaluated inside a square window of tile + 2*halo pixels (shifted
         inwards at the image borders, so a window edge is either >= halo away from the block or IS the image edge),
-        and only the block is kept.  Peak memory follows the window, not the micrograph (4096^2 whole: 82 GB; windows
-        of 2944^2: 42 GB) at the price of evaluating the halos (2.07x the pixels at tile 2048).  ``halo`` must cover
-        the receptive field of blind-spot U-Net + detector; 448 is what tests/test_gpu_pipeline.py validates
-        (tiled == whole to 2e-5).  Everything after the networks (likelihood, posterior mean, sigmoid, NMS) runs on
-        the assembled full-size tensors exactly as in the whole-image path, incl. the GLOBAL mean behind noise_std.
+        and only the block is kept.  Peak memory follows the window, not the micrograph.
+
+        ``halo`` must cover the receptive field: blind-spot U-Net 315 px (upwards, through the five shifted pools,
+        the scale-32 bottleneck and the five nearest-neighbour up-samplings: 4+1, +8+2, +16+4, +32+8, +64+16, +64 at
+        scale 32, then +16+64, +8+32, +4+16, +2+8, +1+4, +1 for the blind-spot shift; in every direction after the
+        four rotations) + 31 px of the filled detector = 346 -> MIN_HALO 352 (window offsets stay multiples of 32, so
+        pooling grids and Winograd tiles of a window coincide with the whole image's).  With the kernel choice pinned
+        (networks.Conv2d: _lib.DT_PIN under no_grad) a window whose planes have the divisibility of the whole image's
+        (sizes that are multiples of 1024) at an offset that is a multiple of 64 (even at scale 32: the 2x2 output
+        tiles of the deepest Winograd level coincide) is computed by the same arithmetic in the same order: the tiled
+        result is then BIT-IDENTICAL to the whole-image one, so the picks are identical (tests/test_gpu_pipeline.py:
+        tile 1024 / halo 512 and tile 1280 / halo 384 on 3072^2); for other sizes and offsets the deepest levels take
+        the direct instead of the Winograd kernel, or another tile phase, and results agree to fp32 rounding.
+        Everything after the networks (likelihood, posterior mean, sigmoid, NMS) runs on the assembled full-size tensors
+        exactly as in the whole-image path, incl. the GLOBAL mean behind noise_std.
         Returns (net_out [1,2,H,W], detector logits [1,1,H,W], noise_std [1,1,1,1])."""
         B, _, H, W = inp.shape
         S = tile + 2 * halo
         if tile % 32 or halo % 32 or H % 32 or W % 32:
             raise ValueError("tiled inference needs tile, halo and the image size to be multiples of 32")
+        if halo < self.MIN_HALO:
+            raise ValueError("halo %d is smaller than the networks' receptive field (%d)" % (halo, self.MIN_HALO))
         if H < S or W < S:
             raise ValueError("image %dx%d is smaller than one window (%d): evaluate it whole" % (H, W, S))
         model, sigma = self.models[Denoiser.MODEL], self.models[Denoiser.SIGMA_ESTIMATOR]
@@ -228,7 +241,7 @@ class Denoiser(nn.Module):
         if style is None or not style.startswith("gauss"):
             raise NotImplementedError("only the gaussian likelihood branch (--noise_style gauss*) is on the hot path")
 
-    def _new_pipeline(self, data, alpha, tau, train, eps=None, eps_flip=None, flip_p=None, tile=None, halo=448, **kwargs):
+    def _new_pipeline(self, data, alpha, tau, train, eps=None, eps_flip=None, flip_p=None, tile=None, halo=512, **kwargs):
         if not len(data) > 2:
             return None  # as the reference: the joint pipeline needs the full batch list (denoiser_v2.py:261)
         self._check_style()

@@ -57,13 +57,22 @@ class FlatGrads:
 
     def compact(self):
         """After one backward pass: parameters that received no gradient (12 tensors of the joint model, SURVEY.md
-        §8a A12) move to the tail of the buffer, so that the collective covers the live prefix only."""
+        §8a A12) move to the tail of the buffer, so that the collective covers the live prefix only.  The gradients
+        of that pass move with their parameters."""
         live = [p for p in self.params if p.grad is not None]
         dead = [p for p in self.params if p.grad is None]
+        old = [p.grad for p in live]           # views of the old buffer: keep it alive until they are copied
         for p in self.params:
             p.grad = None
         self._layout(live + dead, self.flat.device)
         self.live_numel = sum(p.numel() for p in live)
+        # the pass that found the live set already computed this step's gradients: move them to the new layout
+        # instead of running the pass again (a second pass would update the detector's BatchNorm running averages
+        # and draw the reparameterisation noise once more than the reference does in its first step)
+        for p, g in zip(live, old):
+            v = self.views[p.data_ptr()]
+            v.copy_(g)
+            p.grad = v.view(v.shape)
 
     def adopt_strays(self):
         """A parameter used by two operators in one step gets the SUM of their gradients from autograd — a new
@@ -265,7 +274,8 @@ class GraphedTrainStep:
     ``self.grads.all_reduce(world)`` and the optimiser.  ``graph=False`` runs the same step eagerly (same kernels,
     same flat gradients) — the path the roofline leg of bench.py brackets with events."""
 
-    def __init__(self, denoiser, batch, patch, alpha, tau, world=1, mode="joint", graph=True, eager_warmup=2):
+    def __init__(self, denoiser, batch, patch, alpha, tau, world=1, mode="joint", graph=True, eager_warmup=2,
+                 draw_eps=True):
         self.den = denoiser
         self.dev = denoiser.device
         self.alpha, self.tau, self.world, self.mode = alpha, tau, world, mode
@@ -275,6 +285,14 @@ class GraphedTrainStep:
         self.tgt = torch.full((batch, 1), -1.0, dtype=torch.float32, device=self.dev)
         self._tgt_ring = PinnedRing((batch, 1), torch.float32, self.dev)
         self._empty = torch.zeros(0, device=self.dev)
+        # The reparameterisation noise of the two passes (joint_network_v2.py:469-475) lives in static buffers: drawn
+        # inside the pass (captured: torch's graph-safe Philox stream; same draws, same order as the reference's two
+        # randn_like calls), so that what a step used can be read back — or, with draw_eps=False, is whatever the
+        # caller loaded (replaying a recorded step exactly, tests/test_gpu_graph_step.py).
+        self.draw_eps = bool(draw_eps)
+        self.eps = torch.zeros(batch, 1, patch, patch, dtype=torch.float32, device=self.dev)
+        self.eps_flip = torch.zeros(batch, 1, patch, patch, dtype=torch.float32, device=self.dev)
+        self.fallback_reason = None                   # set when a capture failed and the stepper went eager
         self._side = _side_stream(self.dev)           # every forward+backward runs (or is captured) on this stream
         self._graphs = {}
         self._pool = None
@@ -286,7 +304,11 @@ class GraphedTrainStep:
     def _pass(self, flip_p):
         data = DetectionDataset.make_batch(self.inp, self.tgt, hm=self._empty, hm_small=self._empty)
         if self.mode == "joint":
-            o = self.den.run_pipeline(data, self.alpha, self.tau, train=True, flip_p=flip_p)
+            if self.draw_eps:
+                self.eps.normal_()
+                self.eps_flip.normal_()
+            o = self.den.run_pipeline(data, self.alpha, self.tau, train=True, flip_p=flip_p, eps=self.eps,
+                                      eps_flip=self.eps_flip)
         else:
             o = self.den.run_pipeline(data, train=True)
         loss = torch.mean(o[PipelineOutput.LOSS])
@@ -309,12 +331,8 @@ class GraphedTrainStep:
             with self.grads:
                 o = self._pass(flip_p)
             if not self._compacted:
-                self.grads.compact()
+                self.grads.compact()          # this pass's gradients move to the new layout with their parameters
                 self._compacted = True
-                # the first pass wrote to the old layout: redo it so this step's gradients are in place
-                self.grads.begin_step()
-                with self.grads:
-                    o = self._pass(flip_p)
                 self.grads.check_adopted()
         cur.wait_stream(self._side)
         return o
@@ -340,8 +358,14 @@ class GraphedTrainStep:
         self._graphs[axis_key] = (g, o)
 
     # ---- public -----------------------------------------------------------------------------------
-    def load(self, inp, target):
-        """Copy a batch into the static buffers (asynchronously; labels go through a ring of pinned buffers)."""
+    def load(self, inp, target, eps=None, eps_flip=None):
+        """Copy a batch into the static buffers (asynchronously; labels go through a ring of pinned buffers).
+        eps / eps_flip: the reparameterisation noise of the two passes, for a stepper built with draw_eps=False."""
+        if eps is not None or eps_flip is not None:
+            if self.draw_eps:
+                raise ValueError("this stepper draws its own noise (draw_eps=True): loaded eps would be overwritten")
+            self.eps.copy_(eps, non_blocking=True)
+            self.eps_flip.copy_(eps_flip, non_blocking=True)
         self.inp.copy_(inp.to(self.dev, non_blocking=True) if inp.device != self.dev else inp, non_blocking=True)
         t = target if torch.is_tensor(target) else torch.as_tensor(target)
         if t.device.type == "cuda":
@@ -349,10 +373,10 @@ class GraphedTrainStep:
             return
         self._tgt_ring.upload(t.float(), out=self.tgt)
 
-    def prepare(self, inp, target):
+    def prepare(self, inp, target, eps=None, eps_flip=None):
         """Eager warm-up passes (lazy one-time set-up inside the library, the gradient layout) and the capture of
         both flip-axis graphs, on the given batch.  Leaves the gradients of that batch in place."""
-        self.load(inp, target)
+        self.load(inp, target, eps, eps_flip)
         while self._warm > 0:
             self._warm -= 1
             self._eager(0.25)
@@ -360,18 +384,36 @@ class GraphedTrainStep:
             self._eager(0.25)
         if self.use_graph:
             for key, p in (("w", 0.25), ("h", 0.75)):
-                if key not in self._graphs and (self.mode == "joint" or key == "w"):
-                    self._capture(key, p)
+                if key not in self._graphs and (self.mode == "joint" or key == "w") and self.use_graph:
+                    self._try_capture(key, p)
 
-    def __call__(self, inp, target, flip_p=None, eager=False):
-        self.load(inp, target)
+    def _try_capture(self, axis_key, flip_p):
+        """Capture; if the capture raises, the stepper continues EAGERLY in the same process (same kernels, same flat
+        gradients — only the host cost per step differs) and says so once.  Returns True when the graph exists."""
+        try:
+            self._capture(axis_key, flip_p)
+            return True
+        except (RuntimeError, _lib.SprkError) as e:
+            torch_ops.drop_pending(self.dev)
+            ops.set_grad_destinations(None)
+            torch.cuda.synchronize(self.dev)
+            self.use_graph = False
+            self._graphs.clear()
+            self.fallback_reason = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+            import logging
+            logging.getLogger(__name__).warning("HIP-graph capture of the training step failed (%s); continuing with "
+                                                "eager launches", self.fallback_reason)
+            return False
+
+    def __call__(self, inp, target, flip_p=None, eager=False, eps=None, eps_flip=None):
+        self.load(inp, target, eps, eps_flip)
         p = float(np.random.rand()) if flip_p is None else float(flip_p)
         if eager or not self.use_graph or self._warm > 0 or not self._compacted:
             self._warm -= 1
             return self._eager(p)
         key = "w" if (p <= 0.5 or self.mode != "joint") else "h"
-        if key not in self._graphs:
-            self._capture(key, 0.25 if key == "w" else 0.75)
+        if key not in self._graphs and not self._try_capture(key, 0.25 if key == "w" else 0.75):
+            return self._eager(p)
         g, o = self._graphs[key]
         g.replay()
         return o

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._lib import DT_PIN
 from .ops import ACT_LEAKY, ACT_NONE, ACT_RELU
 
 
@@ -72,8 +73,11 @@ class Conv2d(nn.Module):
     def forward(self, x, skip=None, up=False, up_out=False):
         """skip: second input source (channel concat); up: x is half resolution, upsampled on load;
         up_out: write the output nearest-upsampled x2 (the nn.Upsample that follows in the reference)."""
+        # inference (no autograd): the kernel choice is pinned to the layer's structure (_lib.DT_PIN), so that a window
+        # of a micrograph gets the very arithmetic the whole micrograph gets (Denoiser._tiled_networks)
+        dtype = self.mfma_dtype if torch.is_grad_enabled() else (self.mfma_dtype | DT_PIN)
         return ops.conv2d(x, self.weight, self.bias, x2=skip, up1=up, stride=self.stride, dil=self.dilation,
-                          pad=self._pad(), act=self.act, up_out=up_out, dtype=self.mfma_dtype)
+                          pad=self._pad(), act=self.act, up_out=up_out, dtype=dtype)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%d, padding=%d, dilation=%d, act=%d%s" % (

@@ -84,6 +84,7 @@ class DenoiserTrainer:
         self._stepper = None
         self.graph = graph and os.environ.get("SPRK_GRAPH", "1") != "0"
         self._metrics_file = None
+        self._eval_modes_logged = set()
         self.trainfeed, self.testfeed = None, None
 
     # ---- model / optimiser ---------------------------------------------------------------------
@@ -117,7 +118,10 @@ class DenoiserTrainer:
         draws (and, through PatchFeed's seed, the patches) of its first segment."""
         it = int(self.state.get(StateValue.ITERATION, 0) or 0)
         s = (self.seed + 1000 + self.rank + 7919 * it) % (2 ** 31 - 1)
-        torch.manual_seed(s)
+        # only the streams that need a per-rank / per-segment key: torch's CPU generator is left alone (new run: it
+        # continues from the weight initialisation; resume: it continues from the checkpoint's "rng" entry, as the
+        # reference restores it, train.py:936)
+        torch.cuda.manual_seed(s)
         np.random.seed(s)
 
     def init_state(self):
@@ -230,7 +234,13 @@ class DenoiserTrainer:
             eval_history = self.state[StateValue.HISTORY][HistoryValue.EVAL]
             for idx, data in feed:
                 image_count = data[DetectionDataset.INPUT].shape[0]
-                outputs = self.denoiser.run_pipeline(data, train=False, tile=self._eval_tile(data[DetectionDataset.INPUT]))
+                tile, halo = self._eval_tile(data[DetectionDataset.INPUT])
+                shape = tuple(int(v) for v in data[DetectionDataset.INPUT].shape[-2:])
+                if (shape, tile) not in self._eval_modes_logged:
+                    self._eval_modes_logged.add((shape, tile))
+                    logger.info("evaluation of %dx%d inputs: %s", shape[0], shape[1],
+                                "whole image" if tile is None else "halo-tiled, tile %d halo %d" % (tile, halo))
+                outputs = self.denoiser.run_pipeline(data, train=False, tile=tile, halo=halo or 0)
                 eval_history["n"] += image_count
                 clean = outputs[PipelineOutput.INPUTS][DetectionDataset.METADATA][DetectionDataset.Metadata.GT]
                 if len(clean) > 0:   # PSNR against the clean reference images (train.py:404-413)
@@ -240,21 +250,24 @@ class DenoiserTrainer:
                     output_callback(idx, outputs)
         self.denoiser.unfill()
 
-    BYTES_PER_PIXEL_WHOLE = 4900     # peak HBM of the whole-image filled pipeline per input pixel (82 GB at 4096^2)
+    # Whole-image evaluation up to this many pixels (4096^2: 82 GB of the 288 GB of one MI355X), halo-tiled above.
+    # The choice depends on the micrograph's SIZE only — never on what else holds HBM — so the same checkpoint and
+    # micrograph always produce the same *_scores.txt; the mode is written to the log.
+    WHOLE_IMAGE_MAX_PIXELS = 4096 * 4096
+    EVAL_TILE, EVAL_HALO = 3072, 512     # windows of 4096^2: the whole-image kernels, 1.78x the pixels
 
     def _eval_tile(self, inp):
-        """Interior block size for halo-tiled evaluation, or None for the whole-image path: SPRK_EVAL_TILE forces it
-        (0 = never); otherwise tiles of 2048 are used when the whole-image working set would not fit in 80 % of the
-        free HBM (e.g. 8192^2 micrographs: 330 GB)."""
+        """(tile, halo) for halo-tiled evaluation, or (None, None) for the whole-image path.  SPRK_EVAL_TILE =
+        "tile[,halo]" forces tiling (0 = never tile)."""
         H, W = int(inp.shape[-2]), int(inp.shape[-1])
         env = os.environ.get("SPRK_EVAL_TILE")
         if env is not None:
-            t = int(env)
-            return t if t > 0 and min(H, W) >= t + 2 * 448 else None
-        if self.mode != "joint" or min(H, W) < 2048 + 2 * 448:
-            return None
-        free, _ = torch.cuda.mem_get_info(self.device)
-        return 2048 if H * W * self.BYTES_PER_PIXEL_WHOLE > 0.8 * free else None
+            parts = [int(v) for v in env.split(",")]
+            t, h = parts[0], (parts[1] if len(parts) > 1 else self.EVAL_HALO)
+            return (t, h) if t > 0 and min(H, W) >= t + 2 * h else (None, None)
+        if self.mode != "joint" or H * W <= self.WHOLE_IMAGE_MAX_PIXELS or min(H, W) < self.EVAL_TILE + 2 * self.EVAL_HALO:
+            return None, None
+        return self.EVAL_TILE, self.EVAL_HALO
 
     def img_outputs(self, prefix=None):
         """Image outputs of the configured pipeline -> metric names (train.py:763-779)."""

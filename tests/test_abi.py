@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libsprk.so does not export " + n
     assert set(names) == set(_lib.EXPORTS), set(names) ^ set(_lib.EXPORTS)
-    assert L.sprk_version() >= 100
+    assert L.sprk_version() == _lib.ABI_VERSION
 
 
 def test_bad_arguments_are_reported_not_crashed():

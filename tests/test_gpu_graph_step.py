@@ -1,0 +1,241 @@
+"""The TIMED path is the tested path: the HIP-graph-replayed training step (graph_step.GraphedTrainStep: FlatGrads,
+deferred second-stage sums, Philox noise drawn under capture, MultiAdam) against
+
+  * the reference's golden joint steps (tests/golden/joint_train_{w,h}.npz, both flip axes) — replayed, not eager;
+  * the eager step of the same stepper, bit for bit (loss, every output, the whole flat gradient, the detector's
+    BatchNorm running averages), on the first and on later replays;
+  * the oracle run on the noise the stepper drew itself (read back from its static buffers);
+  * three optimiser steps graph + MultiAdam against three eager steps + torch.optim.Adam.
+
+Reference loop: train.py:329-338."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from test_gpu_pipeline import REL, close, make_cfg
+
+pytestmark = pytest.mark.gpu
+
+OUT_KEYS = ("LOSS", "DENOISE_LOSS", "DETECT", "IMG_MU", "IMG_DENOISED", "NOISE_STD_DEV", "MODEL_STD_DEV")
+
+
+def _denoiser(oracle_state, dtype="f32"):
+    from spr_pick_amd import Denoiser
+    den = Denoiser(make_cfg(), device="cuda:0", mode="joint")
+    missing, unexpected = den.load_state_dict({"models." + k: v for k, v in oracle_state.items()}, strict=False)
+    assert not unexpected
+    den.train(); den.unfill()
+    if dtype != "f32":
+        den.set_conv_dtype(dtype)
+    return den
+
+
+def _reset_buffers(den, oracle_state):
+    """BatchNorm running averages back to the fixture's initial state (every pass of the stepper updates them)."""
+    sd = {"models." + k: v for k, v in oracle_state.items() if "running_" in k or "num_batches" in k}
+    den.load_state_dict(sd, strict=False)
+
+
+def _snapshot(stepper, o, den):
+    from spr_pick_amd.params import PipelineOutput as P
+    out = {k: o[getattr(P, k)].detach().clone() for k in OUT_KEYS}
+    out["DETECT_LOSS"] = o[P.DETECT_LOSS].detach().clone()
+    out["AUG_LOSS"] = o[P.AUG_LOSS].detach().clone()
+    out["flat"] = stepper.grads.flat[:stepper.grads.live_numel].clone()
+    out["bn"] = {k: v.clone() for k, v in den.state_dict().items() if torch.is_tensor(v) and ("running_" in k or "num_batches" in k)}
+    return out
+
+
+def _assert_identical(a, b, what):
+    for k in a:
+        if k == "bn":
+            for n in a[k]:
+                assert torch.equal(a[k][n], b[k][n]), "%s: BatchNorm buffer %s differs" % (what, n)
+        else:
+            assert torch.equal(a[k], b[k]), "%s: %s differs (max |d| %.3e)" % (
+                what, k, float((a[k].double() - b[k].double()).abs().max()))
+
+
+def _check_golden(g, snap, den, stepper):
+    """The golden tolerances of tests/test_gpu_pipeline.py::test_joint_train_step_matches_reference."""
+    for key in OUT_KEYS:
+        close(snap[key], g[key], name=key)
+    close(snap["DETECT_LOSS"].reshape(()), g["DETECT_LOSS"], name="DETECT_LOSS")
+    close(snap["AUG_LOSS"].reshape(()), g["AUG_LOSS"], rel=1e-3, name="AUG_LOSS")
+    nograd = set(g["nograd"].tolist())
+    loose = total = 0
+    for name, p in den.models.named_parameters():
+        v = stepper.grads.views[p.data_ptr()]
+        if name in nograd:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None and p.grad.data_ptr() == v.data_ptr(), name
+        key = "grad/" + name
+        off = v.data_ptr() - stepper.grads.flat.data_ptr()
+        a = snap["flat"][off // 4: off // 4 + p.numel()].cpu().numpy().astype(np.float64)
+        absmax = float(g[key + "/absmax"])
+        errs = np.abs(a[g[key + "/idx"]] - g[key + "/val"])
+        assert errs.max() <= 3e-3 * absmax + 1e-4, "%s: probe err %.3e vs max|g| %.3e" % (name, errs.max(), absmax)
+        assert abs(np.linalg.norm(a) / float(g[key + "/norm"]) - 1) < 2e-3 or absmax < 1e-3, name
+        loose += int((errs > 1e-3 * absmax + 1e-6).sum())
+        total += len(errs)
+    assert loose <= total // 1000
+    for k in g.files:
+        if k.startswith("bn_after/"):
+            name = "models.denoiser_model.detector." + k[len("bn_after/"):]
+            close(snap["bn"][name].float(), g[k].astype(np.float64), rel=1e-4, name=name)
+
+
+def test_replayed_step_equals_golden_and_eager_bit_for_bit(oracle_state):
+    """Both flip-axis graphs, injected (golden) noise: replay == golden within the golden tolerances, replay == eager
+    bit for bit (first replay and third), incl. after compact() moved the gradients."""
+    from spr_pick_amd import graph_step
+    den = _denoiser(oracle_state)
+    gw, gh = golden("joint_train_w.npz"), golden("joint_train_h.npz")
+    B = gw["inp"].shape[0]
+    st = graph_step.GraphedTrainStep(den, B, 64, float(gw["alpha"]), float(gw["tau"]), draw_eps=False, eager_warmup=1)
+
+    def batch(g):
+        return (torch.from_numpy(g["inp"]).cuda(), torch.from_numpy(g["target"]),
+                torch.from_numpy(g["eps"]).cuda(), torch.from_numpy(g["eps_flip"]).cuda())
+
+    inp, tgt, eps, epf = batch(gw)
+    # the very first pass finds the live parameters and compact()s: its gradients must already be the step's
+    _reset_buffers(den, oracle_state)
+    o = st(inp, tgt, flip_p=float(gw["flip_p"]), eps=eps, eps_flip=epf)
+    assert st._compacted and st.grads.live_numel == 2106950
+    first = _snapshot(st, o, den)
+    _check_golden(gw, first, den, st)
+    st.prepare(inp, tgt, eps, epf)
+    assert set(st._graphs) == {"w", "h"} and st.fallback_reason is None
+    for g in (gw, gh, gw):
+        inp, tgt, eps, epf = batch(g)
+        p = float(g["flip_p"])
+        _reset_buffers(den, oracle_state)
+        o = st(inp, tgt, flip_p=p, eps=eps, eps_flip=epf, eager=True)
+        eager = _snapshot(st, o, den)
+        snaps = []
+        for rep in range(3):
+            st.grads.flat.fill_(float("nan"))          # a replay must write every live gradient
+            _reset_buffers(den, oracle_state)
+            o = st(inp, tgt, flip_p=p, eps=eps, eps_flip=epf)
+            snaps.append(_snapshot(st, o, den))
+        assert not torch.isnan(snaps[0]["flat"][:st.grads.live_numel]).any()
+        _assert_identical(eager, snaps[0], "replay 1 vs eager")
+        _assert_identical(eager, snaps[2], "replay 3 vs eager")
+        _check_golden(g, snaps[2], den, st)
+    _assert_identical(first, eager, "first (compacting) pass vs a later eager pass")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_replayed_step_with_its_own_noise(oracle_state, dtype):
+    """draw_eps=True (what the trainer and bench.py run): same device seed -> the replay draws the same Philox noise as
+    the eager pass and produces bit-identical results; fp32: the oracle, run on the noise read back from the stepper,
+    agrees at the golden tolerances."""
+    from oracle import pipeline as oracle_pipeline
+    from spr_pick_amd import graph_step
+    den = _denoiser(oracle_state, dtype)
+    g = golden("joint_train_w.npz")
+    inp, tgt = torch.from_numpy(g["inp"]).cuda(), torch.from_numpy(g["target"])
+    alpha, tau = float(g["alpha"]), float(g["tau"])
+    st = graph_step.GraphedTrainStep(den, inp.shape[0], 64, alpha, tau, eager_warmup=1)
+    st.prepare(inp, tgt)
+    for key, p in (("w", 0.25), ("h", 0.75)):
+        _reset_buffers(den, oracle_state)
+        torch.cuda.manual_seed(1234)
+        o = st(inp, tgt, flip_p=p, eager=True)
+        eager = _snapshot(st, o, den)
+        eps_e, epf_e = st.eps.clone(), st.eps_flip.clone()
+        for rep in range(2):
+            _reset_buffers(den, oracle_state)
+            torch.cuda.manual_seed(1234)
+            st.grads.flat.fill_(float("nan"))
+            o = st(inp, tgt, flip_p=p)
+            snap = _snapshot(st, o, den)
+            assert torch.equal(st.eps, eps_e) and torch.equal(st.eps_flip, epf_e), "the replay drew other noise"
+            _assert_identical(eager, snap, "%s replay %d vs eager (%s)" % (key, rep + 1, dtype))
+        assert float(eps_e.std()) > 0.9 and not torch.equal(eps_e, epf_e)
+        o2 = st(inp, tgt, flip_p=p)                  # no re-seed: the stream moves on
+        assert not torch.equal(st.eps, eps_e)
+        if dtype == "f32":
+            sd = {k: v.clone() for k, v in oracle_state.items()}
+            ref = oracle_pipeline.joint_pipeline(sd, inp.cpu(), tgt, alpha, tau, True, eps_e.cpu(), epf_e.cpu(), p)
+            for k in ("LOSS", "DENOISE_LOSS", "DETECT", "IMG_MU", "IMG_DENOISED"):
+                close(eager[k], ref[k].detach().numpy(), name=k)
+            close(eager["DETECT_LOSS"].reshape(()), ref["DETECT_LOSS"].detach().numpy(), name="DETECT_LOSS")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_three_graph_steps_with_multiadam_equal_three_eager_steps_with_torch_adam(oracle_state, dtype):
+    """graph replay + FlatGrads + MultiAdam (the timed loop of bench.py / DenoiserTrainer) against run_pipeline +
+    backward + torch.optim.Adam (the reference's loop, train.py:329-338) on identical batches, noise and flip draws.
+    The gradients of the two loops are bit-identical as long as the parameters are; the two Adam implementations
+    round differently (tests/test_gpu_optim.py), which is what the tolerance covers."""
+    from spr_pick_amd import DetectionDataset, graph_step
+    from spr_pick_amd.params import PipelineOutput as P
+    gws = [golden("joint_train_w.npz"), golden("joint_train_h.npz")]
+    steps = [(gws[0], 0.3), (gws[1], 0.8), (gws[0], 0.6)]
+    a, b = _denoiser(oracle_state, dtype), _denoiser(oracle_state, dtype)
+    B = gws[0]["inp"].shape[0]
+    st = graph_step.GraphedTrainStep(a, B, 64, 0.75, 0.01, draw_eps=False, eager_warmup=1)
+    opt_a = graph_step.make_adam([p for p in a.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99))
+    opt_b = torch.optim.Adam([p for p in b.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99))
+    init = {k: v.clone() for k, v in a.state_dict().items() if torch.is_tensor(v)}
+    g0 = gws[0]
+    st.prepare(torch.from_numpy(g0["inp"]).cuda(), torch.from_numpy(g0["target"]), torch.from_numpy(g0["eps"]).cuda(),
+               torch.from_numpy(g0["eps_flip"]).cuda())
+    a.load_state_dict(init, strict=False)            # prepare() advanced the BatchNorm buffers; parameters untouched
+    losses = []
+    for it, (g, p) in enumerate(steps):
+        inp, tgt = torch.from_numpy(g["inp"]).cuda(), torch.from_numpy(g["target"])
+        eps, epf = torch.from_numpy(g["eps"]).cuda(), torch.from_numpy(g["eps_flip"]).cuda()
+        o = st(inp, tgt, flip_p=p, eps=eps, eps_flip=epf)
+        la = o[P.LOSS].detach().clone()
+        opt_a.step()
+        opt_b.zero_grad(set_to_none=True)
+        ob = b.run_pipeline(DetectionDataset.make_batch(inp, tgt), 0.75, 0.01, train=True, eps=eps, eps_flip=epf, flip_p=p)
+        torch.mean(ob[P.LOSS]).backward()
+        if it == 0:
+            # identical parameters: the replayed gradients ARE the eager gradients, bit for bit
+            for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+                assert (pa.grad is None) == (pb.grad is None), n
+                assert pa.grad is None or torch.equal(pa.grad, pb.grad), n
+        opt_b.step()
+        losses.append((la, ob[P.LOSS].detach().clone()))
+        if it == 0:
+            # ... so after the first update only the two Adam implementations' roundings differ
+            for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+                d = float((pa.detach() - pb.detach()).abs().max())
+                assert d <= 2e-7, "%s differs by %.3e after the first step" % (n, d)
+    assert torch.equal(*losses[0]), "first step: identical parameters must give identical losses"
+    # bf16 operands: the network is chaotic in the operand roundings (a last-bit difference of a weight that
+    # flips one bf16 rounding grows ~3x per layer), so from the second step on the two loops agree to the 16-bit budget only
+    for la, lb in losses[1:]:
+        assert torch.allclose(la, lb, rtol=1e-5 if dtype == "f32" else 2e-2, atol=1e-6)
+    # From the second step on the parameters differ in their last bits, the gradients with them, and Adam is scale-free:
+    # an element whose gradient is near the noise floor (|g| ~ 1e-8 .. 1e-7, where eps = 1e-8 stops normalising) turns a
+    # rounding-level relative change of g into the same relative change of a 1e-4 update.  Measured: max 1.2e-5 on
+    # one element of decode_block_1.0.weight, i.e. 4 % of the 3e-4 the three steps can move a weight; 99.9 % of all
+    # elements agree to 1e-6.
+    moved, worst, n_el, n_off = 0.0, 0.0, 0, 0
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        d = (pa.detach() - pb.detach()).abs()
+        worst = max(worst, float(d.max()))
+        n_el += d.numel()
+        n_off += int((d > 1e-6).sum())
+        moved = max(moved, float((pa.detach() - init[n].to(pa.device)).abs().max()))
+    print("%s: max parameter difference after 3 steps %.2e, %d of %d elements beyond 1e-6" % (dtype, worst, n_off, n_el))
+    if dtype == "f32":
+        assert worst <= 5e-5 and n_off <= n_el // 1000
+    else:
+        # steps 2 and 3 see gradients that differ within the bf16 budget: two updates of <= 1e-4 each, in either direction
+        assert worst <= 4.1e-4
+    assert moved > 1e-4          # the optimiser did move the weights
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        if torch.is_tensor(sa[k]) and "running_" in k:
+            tol = (1e-3, 1e-5) if dtype == "f32" else (5e-2, 1e-3)
+            assert torch.allclose(sa[k], sb[k], rtol=tol[0], atol=tol[1]), (k, float((sa[k] - sb[k]).abs().max()))
+        if torch.is_tensor(sa[k]) and "num_batches" in k:
+            assert int(sa[k]) == int(sb[k]) == 6, (k, int(sa[k]), int(sb[k]))
