@@ -72,9 +72,12 @@ def kernel_source_hash():
 
 
 def cpu_threads():
-    # host cores this process may actually use (the GPU box exposes 256 logical CPUs but grants a share of
-    # them; oversubscribing torch's intra-op pool makes the CPU path orders slower).  SPRK_CPU_THREADS overrides.
-    return min(len(os.sched_getaffinity(0)), int(os.environ.get("SPRK_CPU_THREADS", "16")))
+    # host cores this process may actually use: its affinity mask (BASELINE.md §3 says os.cpu_count(); the GPU box
+    # exposes 256 logical CPUs but grants a share of them, and oversubscribing torch's intra-op pool makes the CPU
+    # path orders slower).  SPRK_CPU_THREADS overrides; the count used is printed in cpu_baseline.cores.
+    if os.environ.get("SPRK_CPU_THREADS"):
+        return int(os.environ["SPRK_CPU_THREADS"])
+    return len(os.sched_getaffinity(0))
 
 
 def cpu_baseline(micrographs, seconds):
@@ -138,7 +141,19 @@ def cpu_inference_baseline(size):
                       "restatement on torch CPU" % (size, size, t1 - t0, t2 - t1, len(s))}
 
 
-def inference_leg(den, dev, size, reps):
+def prof_collect(L, kc):
+    n_, ms_, fl_ = ctypes.c_long(), ctypes.c_double(), ctypes.c_double()
+    L.sprk_prof_collect(kc, ctypes.byref(n_), ctypes.byref(ms_), ctypes.byref(fl_))
+    return n_.value, ms_.value, fl_.value
+
+
+def pick_agreement(a, b):
+    """|A & B| / |A | B| of two coordinate lists [n,2]."""
+    sa = set(map(tuple, a.tolist())); sb = set(map(tuple, b.tolist()))
+    return len(sa & sb) / max(len(sa | sb), 1)
+
+
+def inference_leg(den, dev, size, reps, keep_picks=None):
     """Whole-micrograph filled inference as the evaluator runs it (reference train.py:383-415,557-571): host
     uint8 micrograph -> H2D -> /255 -> JointNetwork filled + sigma net + posterior mean + clamped sigmoid -> NMS
     (r=18, thr 0.02) -> picks back on the host.  H2D and the D2H of the picks are inside the timed region."""
@@ -146,6 +161,7 @@ def inference_leg(den, dev, size, reps):
     from spr_pick_amd.params import PipelineOutput as P
     host_u8 = torch.from_numpy(synthetic.micrograph(7, size=size)[0]).pin_memory()
     zeros = torch.zeros(1, 1)
+    gen = torch.Generator(device=dev)
     den.eval(); den.fill()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     t_net = t_nms = t_h2d = 0.0
@@ -156,7 +172,12 @@ def inference_leg(den, dev, size, reps):
                 ev[0].record()
                 img = host_u8.to(dev, non_blocking=True).to(torch.float32).div_(255.0)[None, None]
                 ev[1].record()
-                oe = den.run_pipeline(DetectionDataset.make_batch(img, zeros), train=False)
+                # the reparameterisation noise (joint_network_v2.py:473) is drawn inside the timed region, from a
+                # generator re-seeded per micrograph: every leg sees the same noise, so pick lists of
+                # different operand precisions can be compared
+                gen.manual_seed(7)
+                eps = torch.randn((1, 1, size, size), dtype=torch.float32, device=dev, generator=gen)
+                oe = den.run_pipeline(DetectionDataset.make_batch(img, zeros), train=False, eps=eps)
                 score = oe[P.DETECT][0, 0]
                 ev[2].record()
                 s, c = nms_device(score, 18, 0.02)
@@ -165,6 +186,8 @@ def inference_leg(den, dev, size, reps):
                 torch.cuda.synchronize()
                 if timed:
                     t_h2d += ev[0].elapsed_time(ev[1]); t_net += ev[1].elapsed_time(ev[2]); t_nms += ev[2].elapsed_time(ev[3])
+                if keep_picks is not None:
+                    keep_picks[:] = [c.numpy().copy()]
                 return len(s)
             once(False)
             torch.cuda.synchronize()
@@ -176,12 +199,40 @@ def inference_leg(den, dev, size, reps):
         den.unfill(); den.train()
     peak_gb = torch.cuda.max_memory_allocated(dev) / 1e9
     torch.cuda.empty_cache()
+    # dominant MFMA kernel of the leg: one more (untimed) repetition with every convolution class bracketed by events
+    from spr_pick_amd import _lib
+    L = _lib.lib()
+    for kc in KCLASS:
+        prof_collect(L, kc)
+    den.eval(); den.fill()
+    try:
+        with torch.no_grad():
+            L.sprk_prof_enable(31)
+            once(False)
+            L.sprk_prof_enable(0)
+    finally:
+        L.sprk_prof_enable(0)
+        den.unfill(); den.train()
+    cls = {kc: prof_collect(L, kc) for kc in KCLASS}
+    dom = max(cls, key=lambda kc: cls[kc][1])
+    n_d, ms_d, fl_d = cls[dom]
+    conv_ms = sum(v[1] for v in cls.values())
+    ach = fl_d / (ms_d * 1e-3) / 1e12 if ms_d > 0 else 0.0
+    roof = {"bound": "mfma", "kernel": KCLASS[dom][0], "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS * KCLASS[dom][1],
+            "unit": "TFLOP/s", "frac": ach / (PEAK_FP32_MFMA_TFLOPS * KCLASS[dom][1]), "launches": n_d,
+            "avg_launch_ms": ms_d / max(n_d, 1), "traffic": None,
+            "share_of_network_ms": ms_d / max(t_net / reps, 1e-9),
+            "all_conv_classes_ms": {KCLASS[k][0]: round(v[1], 3) for k, v in cls.items()},
+            "conv_share_of_network_ms": conv_ms / max(t_net / reps, 1e-9),
+            "events_region": "one extra repetition after the timed ones, every MFMA convolution launch bracketed by HIP "
+                             "events on its stream (operand precision as in the timed repetitions)"}
+    torch.cuda.empty_cache()
     nms_ms = t_nms / reps
     nms_bytes = 4.0 * size * size + 12.0 * n_picks      # read every score once, write the picks
     return {"metric": "inference_mpix_per_sec", "value": size * size / dt / 1e6, "unit": "Mpix/s", "size": [size, size],
             "reps": reps, "ms_per_micrograph": dt * 1e3, "h2d_ms": t_h2d / reps, "network_ms": t_net / reps,
             "includes": "H2D of the uint8 micrograph, network, NMS, D2H of the picks", "picks": int(n_picks),
-            "peak_hbm_gb": peak_gb,
+            "peak_hbm_gb": peak_gb, "roofline": roof,
             "mfma_frac_direct": size * size / dt * FLOP_PER_INFER_PIXEL / (PEAK_FP32_MFMA_TFLOPS * 1e12),
             "nms": {"ms": nms_ms, "radius": 18, "threshold": 0.02, "bytes": nms_bytes,
                     "achieved_gbs": nms_bytes / (nms_ms * 1e-3) / 1e9 if nms_ms > 0 else 0.0,
@@ -207,6 +258,10 @@ def main():
                     help="operand precision of the U-Nets' MFMA convolutions in the headline (timed) region")
     ap.add_argument("--also-dtype", choices=("none", "bf16", "f16"), default="bf16",
                     help="second, shorter timed region with this operand precision (reported under train_<dtype>)")
+    ap.add_argument("--sustain-seconds", type=float, default=5.0,
+                    help="extra back-to-back steps after the timed region until this many seconds (0 = skip)")
+    ap.add_argument("--batch16", choices=("on", "off"), default="on",
+                    help="also time the step at 16 patches per GPU (BASELINE configs[3]'s per-GPU batch)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--infer-size", type=int, default=1024, help="side of the small inference micrograph (0 = skip)")
@@ -306,6 +361,40 @@ def main():
     t_host = (time.perf_counter() - te0) / 6
     fence()
 
+    # sustained leg: at least --sustain-seconds of back-to-back steps whatever --steps was (DVFS steady state on record)
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_sus = max(args.steps, int(np.ceil(args.sustain_seconds / (dt / args.steps))))
+        fence()
+        ts0 = time.perf_counter()
+        for i in range(n_sus):
+            step(args.warmup + args.steps + i)
+        fence()
+        dts = time.perf_counter() - ts0
+        t = torch.tensor([dts], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dts = float(t.item())
+        sustained = {"value": world * batch * n_sus / dts, "unit": "patches/s", "steps": n_sus, "seconds": dts,
+                     "ms_per_step": dts / n_sus * 1e3}
+
+    # the timed path against the eager path, in this very run: one more batch through the graph replay and through the
+    # eager launches of the same stepper — same parameters (no optimiser step in between), same device RNG state, same
+    # flip draw — must give the same loss to the last bit (tests/test_gpu_graph_step.py asserts it for every output and
+    # the whole flat gradient)
+    replay_check = None
+    if use_graph:
+        inp_c, tgt_c = batches[(args.warmup + args.steps) % nb]
+        rng_state = torch.cuda.get_rng_state(dev)
+        o_r = stepper(inp_c, tgt_c, flip_p=0.25)
+        loss_r = o_r[P.LOSS].detach().clone()
+        torch.cuda.set_rng_state(rng_state, dev)
+        o_e = stepper(inp_c, tgt_c, flip_p=0.25, eager=True)
+        loss_e = o_e[P.LOSS].detach().clone()
+        replay_check = {"final_loss_replay": float(loss_r.mean()), "final_loss_eager": float(loss_e.mean()),
+                        "bit_identical": bool(torch.equal(loss_r, loss_e))}
+        del o_r, o_e
+
     if use_graph:
         L.sprk_prof_enable(1 << DOM)
         for i in range(args.event_steps):
@@ -326,6 +415,7 @@ def main():
     all_ms = extra_dom[1] + sum(prof[k][1] for k in others)
     all_fl = extra_dom[2] + sum(prof[k][2] for k in others)
 
+    value_of = {args.dtype: world * batch * args.steps / dt}
     # second training leg: the same step with 16-bit MFMA operands in the U-Nets (BASELINE configs[4]); new graphs
     second = None
     if args.also_dtype not in ("none", args.dtype):
@@ -365,7 +455,45 @@ def main():
                   "note": "same step, U-Net MFMA operands rounded to %s in forward, backward-data and backward-weight (fp32 "
                           "tensors, master weights, accumulation); layers the 16-bit kernels do not cover (1x1 backward-"
                           "weight, planes below 32x32, the detector, the output convolutions) run fp32" % args.also_dtype}
+        value_of[args.also_dtype] = second["value"]
         del o2, st2
+        den.set_conv_dtype(args.dtype)
+
+    # batch 16 per GPU (BASELINE configs[3] = 128 patches over 8 GPUs), same step, own graphs
+    b16 = None
+    if args.batch16 == "on" and batch != 16:
+        b16 = {}
+        bt16 = synthetic.patch_batches(8, 16, mics, seed=200 + rank, device=dev)
+        for dt_name in (args.dtype,) + ((args.also_dtype,) if args.also_dtype not in ("none", args.dtype) else ()):
+            den.set_conv_dtype(dt_name)
+            st16 = graph_step.GraphedTrainStep(den, 16, 64, 0.75, 0.01, world=world, graph=use_graph)
+            st16.grads = stepper.grads
+            st16._compacted = True
+            st16._warm = 1
+            st16.prepare(*bt16[0])
+
+            def step16(i):
+                o16 = st16(*bt16[i % 8])
+                st16.grads.all_reduce(world)
+                opt.step()
+                return o16
+            for i in range(3):
+                step16(i)
+            fence()
+            k16 = max(40, args.steps // 2)
+            t0 = time.perf_counter()
+            for i in range(k16):
+                step16(i)
+            fence()
+            d16 = time.perf_counter() - t0
+            t = torch.tensor([d16], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d16 = float(t.item())
+            ref_rate = value_of[dt_name]
+            b16[dt_name] = {"value": world * 16 * k16 / d16, "unit": "patches/s", "steps": k16, "ms_per_step": d16 / k16 * 1e3,
+                            "frac_of_batch%d_rate" % batch: world * 16 * k16 / d16 / ref_rate}
+            del st16
         den.set_conv_dtype(args.dtype)
 
     infer = infer_large = None
@@ -377,19 +505,26 @@ def main():
             infer = inference_leg(den, dev, args.infer_size, reps=5)
         if args.infer_large:
             torch.cuda.reset_peak_memory_stats(dev)
-            infer_large = inference_leg(den, dev, args.infer_large, reps=3)
+            picks32, picks16 = [], []
+            infer_large = inference_leg(den, dev, args.infer_large, reps=3, keep_picks=picks32)
             infer_large["workload"] = "BASELINE configs[2]: one of the 128 synthetic 4096x4096 micrographs per repetition"
             if args.also_dtype != "none":
                 # same leg with 16-bit MFMA operands in the U-Nets (fp16 for inference: 8x finer than bf16, range is no
                 # issue in the forward pass); picks are then no longer bit-identical to the fp32 path
                 den.set_conv_dtype("f16")
                 torch.cuda.reset_peak_memory_stats(dev)
-                i16 = inference_leg(den, dev, args.infer_large, reps=3)
+                i16 = inference_leg(den, dev, args.infer_large, reps=3, keep_picks=picks16)
                 den.set_conv_dtype(args.dtype)
                 infer_large["f16_operands"] = {k: i16[k] for k in ("value", "unit", "ms_per_micrograph", "network_ms", "picks",
                                                                     "peak_hbm_gb")}
+                infer_large["f16_operands"]["pick_agreement_with_fp32"] = pick_agreement(picks32[0], picks16[0])
+                infer_large["f16_operands"]["pick_agreement_note"] = (
+                    "|A & B| / |A | B| of the coordinate sets after NMS: same micrograph, same reparameterisation noise, fp16 "
+                    "vs fp32 MFMA operands in the U-Nets")
 
     if rank != 0:
+        if dist.is_initialized():
+            dist.destroy_process_group()
         return
     patches = world * batch * args.steps
     value = patches / dt
@@ -423,8 +558,10 @@ def main():
                                                     if args.dtype == "f32" else
                                                     "%s-operand MFMA convolutions in the U-Nets where faster, fp32 elsewhere" % args.dtype),
                    "per_gpu_batch": batch, "global_batch": batch * world, "patch": 64,
-                   "parallelism": "dp%d (in-place flat fp32 gradient all-reduce over RCCL, %d floats)" % (world, stepper.grads.live_numel)
-                                  if world > 1 else "single GPU",
+                   "parallelism": "dp%d (in-place flat fp32 gradient all-reduce over %s, %d floats%s)" % (
+                                      world, distributed.backend_name(), stepper.grads.live_numel,
+                                      "; forced 1-rank collective" if world == 1 else "")
+                                  if stepper.grads.collectives else "single GPU",
                    "execution": ("forward+backward replayed from 2 HIP graphs (one per flip axis, %d kernels each), eager "
                                  "all-reduce + one-launch Adam (sprk_adam_multi)" % (stepper.kernels_per_step or 0)) if use_graph
                                 else "every launch enqueued from Python (--graph off)"},
@@ -457,7 +594,15 @@ def main():
         "host_cpu_ms_per_step": t_cpu / args.steps * 1e3,
         "host_enqueue_wall_ms_per_step": t_enq / args.steps * 1e3,
         "final_loss": last_loss, "kernel_source_hash": khash,
+        "graph_fallback": stepper.fallback_reason,
     }
+    if sustained:
+        out["sustained_patches_per_sec"] = sustained["value"]
+        out["sustained"] = sustained
+    if replay_check:
+        out.update(replay_check)
+    if b16:
+        out["batch16"] = b16
     if second:
         out["train_" + second["dtype"]] = second
     if infer:
@@ -471,6 +616,8 @@ def main():
             out["cpu_baseline"]["inference"] = cpu_inference_baseline(args.infer_size)
             out["inference"]["vs_cpu_baseline"] = infer["value"] / out["cpu_baseline"]["inference"]["value"]
     print(json.dumps(out))
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -14,13 +14,28 @@ import torch
 import torch.distributed as dist
 
 
+def force_collective():
+    """SPRK_DIST_FORCE=1: create the process group and run the gradient collective even at world size 1 — the way to
+    make RCCL initialisation, the collective on the flat gradient buffer and HIP-graph capture beside RCCL's watchdog
+    thread meet each other on a one-GPU box (tests/test_gpu_trainer.py).  A 1-rank all-reduce is the identity."""
+    return os.environ.get("SPRK_DIST_FORCE", "0") == "1"
+
+
+def backend_name():
+    """Name of the active collective library for reports: "RCCL" (torch backend "nccl" on ROCm), "gloo", or None."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    b = dist.get_backend()
+    return "RCCL" if b == "nccl" else b
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*.
-    Returns (rank, world_size, local_rank); a no-op for single-process runs."""
+    Returns (rank, world_size, local_rank); a no-op for single-process runs (unless SPRK_DIST_FORCE=1)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_collective()) and not dist.is_initialized():
         if backend is None:
             # SPRK_DIST_BACKEND=gloo: rehearse the multi-process path on a box with fewer GPUs than ranks
             backend = os.environ.get("SPRK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import _lib, ops, torch_ops
+from . import _lib, distributed, ops, torch_ops
 from .datasets import DetectionDataset
 from .feed import PinnedRing
 from .params import PipelineOutput
@@ -44,6 +44,7 @@ class FlatGrads:
         dev = self.params[0].device
         self._layout(self.params, dev)
         self.live_numel = self.flat.numel()
+        self.collectives = 0          # all-reduces issued (diagnostics / tests)
 
     def _layout(self, order, dev):
         total = sum(p.numel() for p in order)
@@ -115,8 +116,9 @@ class FlatGrads:
 
     def all_reduce(self, world):
         """SUM over ranks, in place (the loss was pre-divided by ``world``)."""
-        if world > 1:
+        if world > 1 or (distributed.force_collective() and dist.is_initialized()):
             dist.all_reduce(self.flat[:self.live_numel], op=dist.ReduceOp.SUM)
+            self.collectives += 1
 
     # While the context is open the backward operators leave the final sums of their two-stage reductions (weight
     # and bias gradients: ~80 five-microsecond launches per step) pending; closing it finishes them in one launch.

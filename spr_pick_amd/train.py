@@ -216,6 +216,13 @@ class DenoiserTrainer:
                         train_history[key.value] += outputs[key] * 255
             self.state[StateValue.ITERATION] += image_count
 
+        st = self._stepper
+        if st is not None:
+            logger.info("step execution: %s; gradient collectives: %d%s",
+                        "eager launches (capture failed: %s)" % st.fallback_reason if st.fallback_reason else
+                        ("HIP-graph replay (%d kernels per step)" % (st.kernels_per_step or 0) if st.use_graph else "eager launches"),
+                        st.grads.collectives,
+                        " over %s, world size %d" % (distributed.backend_name(), self.world) if st.grads.collectives else "")
         logger.info(separator())
         logger.info("TRAINING FINISHED")
         logger.info(separator())

@@ -237,3 +237,45 @@ def test_eval_reports_psnr_against_reference_images(tmp_path):
     assert out.shape == (320, 320) and np.isfinite(psnr) and 0.0 < psnr < 80.0
     log = open(os.path.join(ev.run_dir_path, "log.txt")).read()
     assert "psnr_out=" in log and "psnr_mu_out=" in log
+
+
+def test_rccl_at_world_size_one_bench_and_trainer(tmp_path):
+    """RCCL has to meet this code before an 8-GPU box does (north_star: "RCCL all-reduce of gradients over xGMI").  With
+    SPRK_DIST_FORCE=1 a one-rank process group is created on backend "nccl" (= RCCL on ROCm) and the in-place
+    all-reduce of the flat gradient buffer runs every step: RCCL initialisation, torch.cuda.set_device ordering, the
+    HIP-graph capture in "thread_local" mode beside RCCL's watchdog thread, and replay + collective + Adam in a loop —
+    for bench.py (which also checks replay == eager in-process) and for the `joint train start` CLI."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def env():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        e = dict(os.environ, SPRK_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=root)
+        e.pop("SPRK_DIST_BACKEND", None)
+        return e
+
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--infer-size", "0",
+                        "--infer-large", "0", "--no-cpu-baseline", "--also-dtype", "none", "--sustain-seconds", "0",
+                        "--batch16", "off", "--event-steps", "1"], env=env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "RCCL" in out["config"]["parallelism"] and "forced 1-rank" in out["config"]["parallelism"], out["config"]
+    assert "HIP graphs" in out["config"]["execution"] and out["graph_fallback"] is None
+    assert out["bit_identical"] is True and np.isfinite(out["final_loss"]) and out["value"] > 100
+
+    imgs, lab = _write_set(str(tmp_path))
+    runs = str(tmp_path / "runs")
+    r = subprocess.run([sys.executable, "-m", "spr_pick_amd"] +
+                       ("train start -a ssdn -n gaussian --noise_value var -t %s -l %s -ap 0.75 -tau 0.01 -iter 96 "
+                        "--train_batch_size 16 --print_interval 32 --checkpoint_interval 96 --runs_dir %s"
+                        % (imgs, lab, runs)).split(), env=env(), capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    run = os.path.join(runs, os.listdir(runs)[0])
+    log = open(os.path.join(run, "log.txt")).read()
+    assert "HIP-graph replay" in log and "gradient collectives: 6 over RCCL, world size 1" in log, log[-1500:]
