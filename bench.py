@@ -71,13 +71,36 @@ def kernel_source_hash():
     return h.hexdigest()[:12]
 
 
-def cpu_threads():
-    # host cores this process may actually use: its affinity mask (BASELINE.md §3 says os.cpu_count(); the GPU box
-    # exposes 256 logical CPUs but grants a share of them, and oversubscribing torch's intra-op pool makes the CPU
-    # path orders slower).  SPRK_CPU_THREADS overrides; the count used is printed in cpu_baseline.cores.
+def cpu_share():
+    """(threads to use, affinity count, cgroup quota or None).  The GPU box shows 256 logical CPUs in the affinity mask
+    but grants one GPU's share of them (16: the pool's rule for worker pools); a torch intra-op pool sized to the mask
+    is oversubscribed ~16x and the CPU path becomes orders slower (measured in round 2, and again this round: the
+    baseline did not finish in 7 minutes).  So: min(affinity, cgroup cpu.max quota if one is set, 16); SPRK_CPU_THREADS
+    overrides.  All three numbers are printed in cpu_baseline."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                quota = max(1, int(round(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
     if os.environ.get("SPRK_CPU_THREADS"):
-        return int(os.environ["SPRK_CPU_THREADS"])
-    return len(os.sched_getaffinity(0))
+        return int(os.environ["SPRK_CPU_THREADS"]), aff, quota
+    return min(aff, quota or aff, 16), aff, quota
+
+
+def cpu_threads():
+    return cpu_share()[0]
+
+
+def log(msg):
+    """Progress to stderr (the JSON line on stdout stays alone): a silent run looks hung to the GPU pool's guard."""
+    print("[bench %7.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
 
 
 def cpu_baseline(micrographs, seconds):
@@ -115,7 +138,9 @@ def cpu_baseline(micrographs, seconds):
         if time.perf_counter() - t0 >= seconds or n >= 64:
             break
     dt = time.perf_counter() - t0
-    return {"value": 4 * n / dt, "unit": "patches/s", "cores": threads, "kind": "port",
+    _, aff, quota = cpu_share()
+    return {"value": 4 * n / dt, "unit": "patches/s", "cores": threads, "affinity_cpus": aff, "cgroup_quota_cpus": quota,
+            "kind": "port",
             "sample": "%d optimisation steps of batch 4 (64x64 patches, same synthetic micrographs) in %.1f s; "
                       "oracle/ restatement on torch CPU" % (n, dt)}
 
@@ -327,6 +352,7 @@ def main():
         step(i, eager=True)
     fence()
     L.sprk_prof_enable(0)
+    log("eager warm-up done")
     warm = {kc: collect(kc) for kc in KCLASS}
     DOM = max(KCLASS, key=lambda kc: warm[kc][1])
     stepper.prepare(*batches[0])     # captures both flip-axis graphs (no-op with --graph off)
@@ -346,6 +372,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     L.sprk_prof_enable(0)
+    log("timed region done: %.1f ms per step" % (dt / args.steps * 1e3))
     launches = L.sprk_launch_count() - launches0
     last_loss = float(torch.mean(o[P.LOSS].detach()))
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -378,6 +405,7 @@ def main():
         sustained = {"value": world * batch * n_sus / dts, "unit": "patches/s", "steps": n_sus, "seconds": dts,
                      "ms_per_step": dts / n_sus * 1e3}
 
+    log("sustained leg done")
     # the timed path against the eager path, in this very run: one more batch through the graph replay and through the
     # eager launches of the same stepper — same parameters (no optimiser step in between), same device RNG state, same
     # flip draw — must give the same loss to the last bit (tests/test_gpu_graph_step.py asserts it for every output and
@@ -415,6 +443,7 @@ def main():
     all_ms = extra_dom[1] + sum(prof[k][1] for k in others)
     all_fl = extra_dom[2] + sum(prof[k][2] for k in others)
 
+    log("event legs done")
     value_of = {args.dtype: world * batch * args.steps / dt}
     # second training leg: the same step with 16-bit MFMA operands in the U-Nets (BASELINE configs[4]); new graphs
     second = None
@@ -459,6 +488,7 @@ def main():
         del o2, st2
         den.set_conv_dtype(args.dtype)
 
+    log("second dtype leg done")
     # batch 16 per GPU (BASELINE configs[3] = 128 patches over 8 GPUs), same step, own graphs
     b16 = None
     if args.batch16 == "on" and batch != 16:
@@ -496,6 +526,7 @@ def main():
             del st16
         den.set_conv_dtype(args.dtype)
 
+    log("batch-16 leg done")
     infer = infer_large = None
     if rank == 0:
         del o
@@ -503,6 +534,7 @@ def main():
         torch.cuda.reset_peak_memory_stats(dev)
         if args.infer_size:
             infer = inference_leg(den, dev, args.infer_size, reps=5)
+        log("inference leg done")
         if args.infer_large:
             torch.cuda.reset_peak_memory_stats(dev)
             picks32, picks16 = [], []
@@ -609,8 +641,10 @@ def main():
         out["inference"] = infer
     if infer_large:
         out["inference_large"] = infer_large
+    log("GPU legs done")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(mics, args.cpu_seconds)
+        log("CPU training baseline done")
         out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         if args.infer_size:
             out["cpu_baseline"]["inference"] = cpu_inference_baseline(args.infer_size)

@@ -122,6 +122,15 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y,
 size_t sprk_conv2d_bwd_data_ws_bytes(const sprk_conv_geom *g);
 int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk_conv_geom *g,
                          void *ws, size_t ws_bytes, void *stream);
+/* The same with the activation backward of the layer that PRODUCED this convolution's input fused in:
+ *   gin = (d loss / d conv input) * act'(mask_y),   mask_y = the saved conv input [N,C1+C2,Hin,Win] (post-activation
+ * output of that layer), mask_act = its SPRK_ACT_*.  gin is then that layer's pre-activation gradient and its own
+ * sprk_act_bwd pass (read gy, read y, write gpre) is not needed; only its bias gradient remains (sprk_act_bwd with
+ * SPRK_ACT_NONE: one read).  In conv -> conv chains (joint_network_v2.py:33-97: every block of the U-Nets) this removes
+ * two thirds of the activation-backward traffic.  The Winograd kernel applies the mask in its output transform; the
+ * other kernels finish with an in-place pass, so the call is valid for every geometry without upsampled input. */
+int sprk_conv2d_bwd_data_masked(const float *gy, const float *w, float *gin, const sprk_conv_geom *g,
+                                const float *mask_y, int mask_act, void *ws, size_t ws_bytes, void *stream);
 /* gw[Cout][C1+C2][KH][KW] = d loss / d w  (overwritten, not accumulated) */
 size_t sprk_conv2d_bwd_weight_ws_bytes(const sprk_conv_geom *g);
 int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, float *gw,
@@ -173,7 +182,10 @@ int sprk_concat_up_bwd(const float *gin, float *ga, float *gb, int N, int C1, in
  * Shift2d((1,0)) + MaxPool2d(2): models/joint_network_v2.py:27-30, models/utility.py:46-72;
  * shift = 0 gives the plain MaxPool2d(2) of the sigma net (joint_network_v2_shallow.py). */
 int sprk_shift_maxpool2_fwd(const float *x, float *y, int NC, int H, int W, int shift, void *stream);
-int sprk_shift_maxpool2_bwd(const float *gy, const float *x, float *gx, int NC, int H, int W, int shift, void *stream);
+/* act != SPRK_ACT_NONE: x is the post-activation output of a convolution consumed by this pool only; gx is multiplied
+ * by act'(x) and is then that convolution's PRE-activation gradient (its sprk_act_bwd pass reduces to the bias sum) */
+int sprk_shift_maxpool2_bwd(const float *gy, const float *x, float *gx, int NC, int H, int W, int shift, int act,
+                            void *stream);
 /* rotate(x,{0,90,180,270}) + cat(dim=0): joint_network_v2.py:198-200, utils/data.py:43-68.
  * x [B,C,P,P] -> y [4B,C,P,P]; bwd sums the four inverse rotations into gx. */
 int sprk_rot4_stack_fwd(const float *x, float *y, int B, int C, int P, void *stream);

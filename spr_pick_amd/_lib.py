@@ -4,7 +4,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsprk.so")
+LIB_PATH = os.environ.get("SPRK_LIB") or os.path.join(_HERE, "libsprk.so")   # SPRK_LIB: kernel A/B experiments
 
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2          # SPRK_DT_*: precision of the MFMA operands (include/sprk.h)
@@ -55,6 +55,7 @@ _SIGS = {
     "sprk_conv2d_fwd": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue), c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_data_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_bwd_data": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
+    "sprk_conv2d_bwd_data_masked": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_f, c_i, c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_weight_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_bwd_weight": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_weight_partial": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, ctypes.POINTER(ReduceItem), c_vp]),
@@ -64,7 +65,7 @@ _SIGS = {
     "sprk_act_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_long, c_vp, c_sz, c_vp]),
     "sprk_concat_up_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "sprk_shift_maxpool2_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),
-    "sprk_shift_maxpool2_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),
+    "sprk_shift_maxpool2_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "sprk_rot4_stack_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
     "sprk_rot4_stack_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
     "sprk_unrot4_shift_concat_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),

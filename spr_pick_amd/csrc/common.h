@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/sprk.h"
 
@@ -66,6 +67,21 @@ inline int ew_blocks(long n, int threads = 256) {
     return (int)b;
 }
 
+}  // namespace sprk
+
+// XCD-aware start slot of a persistent workgroup.  Workgroups are dispatched round-robin over the 8 XCDs (id % 8), each
+// with its own L2; work items that share input rows (spatially adjacent tiles / regions) should therefore go to
+// workgroups of the SAME XCD.  With the workgroups walking items  slot + t * nwg  (t = 0, 1, ...), slot = xcd_slot(id)
+// gives XCD k the contiguous items [k * nwg / 8, (k + 1) * nwg / 8) of every round instead of every 8th item.
+__device__ __forceinline__ int xcd_slot(int id, int nwg, int on) {
+    if (!on || (nwg & 7)) return id;
+    return (id & 7) * (nwg >> 3) + (id >> 3);
+}
+namespace sprk {
+inline int xcd_on() {
+    static const int on = getenv("SPRK_XCD") ? atoi(getenv("SPRK_XCD")) : 1;   // debug: 0 = plain round-robin order
+    return on;
+}
 }  // namespace sprk
 
 // exact floor(a / d) for 0 <= a < 2^21 via a float reciprocal (inv = 1.0f / d)

@@ -1447,8 +1447,20 @@ size_t sprk_conv2d_bwd_data_ws_bytes(const sprk_conv_geom *g) {
 
 int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk_conv_geom *g, void *ws,
                          size_t ws_bytes, void *stream) {
+    return sprk_conv2d_bwd_data_masked(gy, w, gin, g, nullptr, SPRK_ACT_NONE, ws, ws_bytes, stream);
+}
+
+// in-place mask of a finished gradient (the layers whose backward-data kernel has no masked epilogue)
+static int mask_in_place(float *gin, const float *mask_y, int mask_act, const sprk_conv_geom *g, hipStream_t s) {
+    return sprk_act_bwd(gin, mask_y, gin, nullptr, mask_act, g->N, g->C1 + g->C2, g->Hin, g->Win, 0, 0, nullptr, 0, s);
+}
+
+int sprk_conv2d_bwd_data_masked(const float *gy, const float *w, float *gin, const sprk_conv_geom *g,
+                                const float *mask_y, int mask_act, void *ws, size_t ws_bytes, void *stream) {
     if (int rc = check_geom(g)) return rc;
     SPRK_REQUIRE(gy && w && gin, "conv2d_bwd_data: null tensor");
+    SPRK_REQUIRE(mask_act == SPRK_ACT_NONE || (mask_y && !g->up1), "conv2d_bwd_data: mask needs the saved input, no upsampling");
+    if (mask_act == SPRK_ACT_NONE) mask_y = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const int Cin = g->C1 + g->C2;
     if (naive_of(g) || g->stride != 1) {
@@ -1456,12 +1468,16 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
         DirectArgs a{nullptr, nullptr, w, gy, gin, *g, e0};
         const long total = (long)g->N * Cin * g->Hin * g->Win;
         hipLaunchKernelGGL(conv_bwd_data_direct_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, s, a);
-        return sprk::check_launch("conv_bwd_data_direct");
+        if (int rc = sprk::check_launch("conv_bwd_data_direct")) return rc;
+        return mask_y ? mask_in_place(gin, mask_y, mask_act, g, s) : (int)SPRK_OK;
     }
     // gin = correlation of gy with the flipped, channel-transposed kernel
     if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !naive_of(g)) {
         const sprk::Conv16Call c16 = call16_bwd(g);
-        if (sprk::conv16_eligible(c16)) return sprk::conv16_run(c16, gy, nullptr, w, gin, ws, ws_bytes, s);
+        if (sprk::conv16_eligible(c16)) {
+            if (int rc = sprk::conv16_run(c16, gy, nullptr, w, gin, ws, ws_bytes, s)) return rc;
+            return mask_y ? mask_in_place(gin, mask_y, mask_act, g, s) : (int)SPRK_OK;
+        }
     }
     if (sprk::wino_eligible(wino_geom_bwd(g))) {
         const size_t need = sprk::wino_ws_bytes(g->Cout, 0, Cin);
@@ -1472,6 +1488,8 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
         sprk::WinoArgs wa{gy, nullptr, w, nullptr, nullptr, nullptr, gin, (float *)ws, g->N, g->Cout, 0, g->Hout, g->Wout,
                           Cin, (g->KH - 1) * g->dil - g->pad_top, (g->KW - 1) * g->dil - g->pad_left, SPRK_ACT_NONE, 1,
                           Cin > 48 ? kClassWino : 2, 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * 9};
+        wa.mask = mask_y;          // d act / d y of the layer that produced this conv's input, applied in the output
+        wa.mask_act = mask_act;    // transform: gin leaves the kernel as that layer's pre-activation gradient
         if (int rc = sprk::wino_conv(wa, s)) return rc;
         return sprk::check_launch("wino_conv(bwd_data)");
     }
@@ -1501,7 +1519,8 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
     sprk::prof_begin(kclass, flops, s);
     if (int rc = launch_fwd(a, p, s)) return rc;
     sprk::prof_end(kclass, s);
-    return sprk::check_launch("conv_mfma(bwd_data)");
+    if (int rc = sprk::check_launch("conv_mfma(bwd_data)")) return rc;
+    return mask_y ? mask_in_place(gin, mask_y, mask_act, g, s) : (int)SPRK_OK;
 }
 
 size_t sprk_conv2d_bwd_weight_ws_bytes(const sprk_conv_geom *g) {

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
     // The workgroup is persistent: tiles blockIdx.x, + gridDim.x, ...  After a tile's last chunk the NEXT tile's first
     // fetch and weight chunk are issued before this tile's stores, so the stores of one tile and the loads of the next
     // share the memory system instead of taking turns.
-    int tile = blockIdx.x;
+    int tile = xcd_slot(blockIdx.x, gridDim.x, a.xcdRemap);   // gridDim.x <= ntiles: the slot is a valid tile
     if (tile >= ntiles) return;
     setup(tile);
     fetch(0);
@@ -906,7 +906,7 @@ static int run_tile(const Conv16Call &c, const PlanT &p, const float *x, const f
     a.Cout = c.Cout; a.Hout = c.Hout; a.Wout = c.Wout; a.KH = 3; a.KW = 3; a.stride = 1; a.dil = 1;
     a.padT = c.padT; a.padL = c.padL; a.act = c.act;
     a.lgTC = p.lgTC; a.lgTR = p.lgTR; a.tilesX = p.tilesX; a.tilesY = p.tilesY;
-    a.vec4 = 1; a.up2 = c.up2;
+    a.vec4 = 1; a.up2 = c.up2; a.xcdRemap = xcd_on();
     k.w16 = ws;
     k.G4 = p.G4; k.nchunks = p.nchunks;
     k.ngFull = 18;

@@ -38,9 +38,10 @@ __global__ void shift_maxpool2_fwd_kernel(const float *__restrict__ x, float *__
 // one thread per x element: it receives the window's gradient iff it is the FIRST maximum of
 // its window in row-major order (torch's max_pool2d backward rule).
 __global__ void shift_maxpool2_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x,
-                                          float *__restrict__ gx, int NC, int H, int W, int shift) {
+                                          float *__restrict__ gx, int NC, int H, int W, int shift, int act) {
     const int Ho = H >> 1, Wo = W >> 1;
     const long total = (long)NC * H * W;
+    const float neg = act == SPRK_ACT_LEAKY ? 0.1f : 0.f;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         long t = e;
         const int v0 = (int)(t % W); t /= W;
@@ -64,6 +65,7 @@ __global__ void shift_maxpool2_bwd_kernel(const float *__restrict__ gy, const fl
             const int mine = ((u & 1) << 1) | (v0 & 1);
             if (best == mine) g = gy[(nc * Ho + i) * Wo + j];
         }
+        if (act != SPRK_ACT_NONE && !(x[e] > 0.f)) g *= neg;
         gx[e] = g;
     }
 }
@@ -82,7 +84,8 @@ __device__ __forceinline__ int first_max4(float a, float b, float c, float d) {
 
 __global__ __launch_bounds__(256) void shift_maxpool2_bwd_v4_kernel(const float *__restrict__ gy,
                                                                     const float *__restrict__ x, float *__restrict__ gx,
-                                                                    int NC, int H, int W, int shift) {
+                                                                    int NC, int H, int W, int shift, int act) {
+    const float neg = act == SPRK_ACT_LEAKY ? 0.1f : 0.f;
     const int Ho = H >> 1, Wo = W >> 1, W4 = W >> 2;
     const int per = H * W4;
     for (int nc = blockIdx.y; nc < NC; nc += gridDim.y) {
@@ -103,6 +106,13 @@ __global__ __launch_bounds__(256) void shift_maxpool2_bwd_v4_kernel(const float 
                 out.y = b0 == k0 + 1 ? g.x : 0.f;
                 out.z = b1 == k0 ? g.y : 0.f;
                 out.w = b1 == k0 + 1 ? g.y : 0.f;
+                if (act != SPRK_ACT_NONE) {   // this thread's own x row: A for the window's first row, B for the second
+                    const float4 X = (u & 1) ? B : A;
+                    out.x *= X.x > 0.f ? 1.f : neg;
+                    out.y *= X.y > 0.f ? 1.f : neg;
+                    out.z *= X.z > 0.f ? 1.f : neg;
+                    out.w *= X.w > 0.f ? 1.f : neg;
+                }
             }
             *reinterpret_cast<float4 *>(gx + (long)nc * H * W + (long)r0 * W + 4 * q) = out;
         }
@@ -514,17 +524,18 @@ int sprk_shift_maxpool2_fwd(const float *x, float *y, int NC, int H, int W, int 
     return sprk::check_launch("shift_maxpool2_fwd");
 }
 
-int sprk_shift_maxpool2_bwd(const float *gy, const float *x, float *gx, int NC, int H, int W, int shift, void *stream) {
+int sprk_shift_maxpool2_bwd(const float *gy, const float *x, float *gx, int NC, int H, int W, int shift, int act,
+                            void *stream) {
     SPRK_REQUIRE(gy && x && gx && NC > 0 && H >= 2 && W >= 2 && shift >= 0, "shift_maxpool2_bwd: bad arguments");
     const long total = (long)NC * H * W;
     if (W % 4 == 0 && H % 2 == 0 && ((((uintptr_t)x | (uintptr_t)gx) & 15) == 0) && (((uintptr_t)gy & 7) == 0)) {
         const int per = H * (W / 4);
         dim3 grid(std::min(sprk::cdiv(per, 256), 64), std::min(NC, 32768));
-        hipLaunchKernelGGL(shift_maxpool2_bwd_v4_kernel, grid, dim3(256), 0, (hipStream_t)stream, gy, x, gx, NC, H, W, shift);
+        hipLaunchKernelGGL(shift_maxpool2_bwd_v4_kernel, grid, dim3(256), 0, (hipStream_t)stream, gy, x, gx, NC, H, W, shift, act);
         return sprk::check_launch("shift_maxpool2_bwd_v4");
     }
     hipLaunchKernelGGL(shift_maxpool2_bwd_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, gy,
-                       x, gx, NC, H, W, shift);
+                       x, gx, NC, H, W, shift, act);
     return sprk::check_launch("shift_maxpool2_bwd");
 }
 

@@ -60,7 +60,7 @@ struct Wg16Args {
     int nUnits;              // N * regX * seg
     int xcs;                 // bytes per input channel of the rolling x buffer (SLOTS rows x pitch x 2, bank spread)
     int tail;                // 1: the last input channel (Cin = 48 k + 1) rides in block 0 as plane 48 (see below)
-    int diag;
+    int diag, xcd;
 };
 
 // LGRW: log2 of the region width (6: 2 rows x 64 columns, 5: 4 rows x 32 columns, 4: 8 rows x 16 columns).
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     const int ttap = min(l15, 8), tky = ttap / 3, tkx = ttap - tky * 3;
     const int tlane = ldsX + kCB * a.xcs + (8 + tkx - a.padL + kcol) * 2;
 
-    for (int u = blockIdx.x; u < a.nUnits; u += gridDim.x) {
+    for (int u = xcd_slot(blockIdx.x, gridDim.x, a.xcd); u < a.nUnits; u += gridDim.x) {
         const int sgi = u % a.seg;
         const int t = u / a.seg;
         const int cx = t % a.regX, n = t / a.regX;
@@ -611,6 +611,7 @@ int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const flo
     a.regX = p.regX; a.regY = p.regY; a.seg = p.seg; a.segLen = p.segLen; a.nUnits = p.nUnits; a.xcs = p.xcs; a.tail = p.tail;
     static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
     a.diag = diag;
+    a.xcd = xcd_on();
     const int dt = c.dtype & SPRK_DT_MASK;
     dim3 grid(p.parts, p.nBlocks);
     auto go = [&](auto kernel) {

@@ -19,6 +19,8 @@ struct WinoArgs {
     int kclass;            // profiling class of the main kernel launch (sprk_prof_*)
     double flops;          // algorithmic (direct-convolution) FLOPs of this call, for the same
     int up2;               // 1: y is [N,Cout,2H,2W], every output written to its 2x2 block (fused nn.Upsample)
+    const float *mask = nullptr;   // [N,Cout,H,W] or null: y *= d act / d (mask) (backward-data: the saved conv input)
+    int mask_act = 0;              // SPRK_ACT_* of that mask
 };
 
 struct WinoWgArgs {

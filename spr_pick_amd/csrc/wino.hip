@@ -26,6 +26,9 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned fbits(float v) { return __builtin_bit_cast(unsigned, v); }
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int kXZero = (int)0x80000000;   // beyond num_records: the DMA writes zeros
@@ -70,13 +73,15 @@ static_assert(CK * Geo<0>::RPLANE <= RAWF && CK * Geo<1>::RPLANE <= RAWF, "raw t
 constexpr int ETS = 68;                                // exchange stride per channel: 64 tiles + 4
 constexpr int kThreads = 512;
 constexpr int kEFloats = 4 * 2 * 32 * ETS;
+constexpr int kECFloats = 2 * 96;                      // per-channel (scale, shift) of the workgroup's channel group
 
 // U of one chunk: [pos][nt][k][16]: the 64 lanes of a B read (k = lane / 16, channel = lane % 16) hit 64
 // consecutive floats (no padding, no bank conflicts), and every (pos, nt) operand sits a multiple of 256 bytes
 // from the lane's base address, which is what ds_read2st64_b32 encodes as an immediate
 __host__ __device__ constexpr int ufloats_of(int NT) { return 16 * NT * CK * 16; }
 __host__ __device__ constexpr size_t lds_bytes_of(int NT) {
-    return (size_t)(2 * RAWF + 2 * ufloats_of(NT) + kEFloats) * 4;   // two stages + the output-transform exchange
+    return (size_t)(2 * RAWF + 2 * ufloats_of(NT) + kEFloats + kECFloats) * 4;   // two stages + the output-transform
+                                                                                // exchange + epilogue constants
 }
 
 // U[group][chunk][pos][nt][k][16] = (G g G^T)[pos] of the tap matrix of (output channel (group*NT + nt)*16 + j,
@@ -132,9 +137,9 @@ struct IC {
 };
 
 struct KArgs {
-    const float *x, *x2, *U, *bias, *scale, *shift;
+    const float *x, *x2, *U, *bias, *scale, *shift, *mask;
     float *y;
-    int N, C1, C2, H, W, Cout, padT, padL, act, tilesX, tilesY, ntiles, nc1, nch, up2;
+    int N, C1, C2, H, W, Cout, padT, padL, act, tilesX, tilesY, ntiles, nc1, nch, up2, xcd, diag, mact;
 };
 
 template <int NT, int SQ>
@@ -149,6 +154,23 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     const int pg = wave & 3, th = wave >> 2;
     const int grp = blockIdx.y;
     const long HW = (long)a.H * a.W;
+    // per-channel epilogue constants of this channel group, once per workgroup: v * EC[c] + EC[96 + c] (a load inside
+    // the output transform would put a memory round trip on the critical path of every tile)
+    float *EC = smem + 2 * UFLOATS + 2 * RAWF + kEFloats;
+    if (tid < NT * 16) {
+        const int co = grp * (NT * 16) + tid;
+        float sc = 1.f, sh = 0.f;
+        if (co < a.Cout) {
+            if (a.scale) {
+                sc = a.scale[co];
+                sh = a.shift[co];
+            } else if (a.bias) {
+                sh = a.bias[co];
+            }
+        }
+        EC[tid] = sc;
+        EC[96 + tid] = sh;
+    }
 
     // raw-tile DMA: lane q moves 16 bytes of plane q / (RPLANE/4), row and column group from the remainder.
     // The workgroup is persistent (tiles blockIdx.x, + gridDim.x, ...): the lane keeps its position inside the raw
@@ -223,24 +245,30 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
             av[mt][3] = xv[1] - xv[3];
         }
     };
-    auto mma = [&](const float (&av)[2][4], auto stage) {
-        constexpr int S = decltype(stage)::value;
+    // first: the tile's first chunk — the C operand is the constant 0 instead of 192 accumulator registers cleared
+    // by 192 VALU moves per tile (each of which costs MFMA issue time)
+    auto mfma12 = [&](const float (&av)[2][4], const float (&bv)[NT], auto pos, auto first) {
+        constexpr int p = decltype(pos)::value;
+        constexpr bool FIRST = decltype(first)::value != 0;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (FIRST)
+                    acc[p][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][p], bv[nt], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                else
+                    acc[p][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][p], bv[nt], acc[p][mt][nt], 0, 0, 0);
+            }
+    };
+    auto loadb = [&](float (&bv)[NT], auto stage, auto pos) {
+        constexpr int S = decltype(stage)::value, p = decltype(pos)::value;
         const lds_cfp bp = lds_f(bbase);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float bv[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[S * UFLOATS + (p * NT + nt) * 64];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[p][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][p], bv[nt], acc[p][mt][nt], 0, 0, 0);
-        }
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[S * UFLOATS + (p * NT + nt) * 64];
     };
 
     const int nch = a.nch;
-    int tile = blockIdx.x;
+    int tile = xcd_slot(blockIdx.x, gridDim.x, a.xcd);
     set_tile(tile);
     issue_raw(0, Rb);
     issue_u(0, Ub);
@@ -251,25 +279,54 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     transform(IC<0>{}, aop[0]);
     __syncthreads();
     // iteration c: aop[c&1] = operands of chunk c, U[c&1] holds chunk c, raw[(c+1)&1] the raw tile of chunk c+1
-    auto iter = [&](auto par, int c) {
+    auto iter = [&](auto par, int c, auto first) {
         constexpr int P = decltype(par)::value;
         if (c + 1 < nch) issue_u(c + 1, Ub + (1 - P) * UFLOATS);
         if (c + 2 < nch) issue_raw(c + 2, Rb + P * RAWF);
-        transform(IC<1 - P>{}, aop[1 - P]);   // past the last chunk this reads a stale tile: never used
-        mma(aop[P], IC<P>{});
+        // the first position's 12 MFMAs go out before the next chunk's input transform: its LDS reads and ~40 VALU
+        // instructions then run while the matrix pipe works, instead of in front of an idle pipe (both waves of a SIMD
+        // leave the barrier together, so neither covers the other's stall)
+        float b0[NT], b1[NT];
+        if constexpr (NT == 6) {
+            // next chunk's input transform, then the four positions
+            transform(IC<1 - P>{}, aop[1 - P]);   // past the last chunk this reads a stale tile: never used
+            loadb(b0, IC<P>{}, IC<0>{}); mfma12(aop[P], b0, IC<0>{}, first);
+            loadb(b0, IC<P>{}, IC<1>{}); mfma12(aop[P], b0, IC<1>{}, first);
+            loadb(b0, IC<P>{}, IC<2>{}); mfma12(aop[P], b0, IC<2>{}, first);
+            loadb(b0, IC<P>{}, IC<3>{}); mfma12(aop[P], b0, IC<3>{}, first);
+            (void)b1;
+        } else {
+            // 48-channel layers (24 MFMAs per chunk and wave: LDS latency weighs twice as much): the B operands of
+            // position p + 1 are in flight while position p is multiplied, and the input transform of the next chunk
+            // sits between positions 0 and 1.  Same-box A/B (scratch/r3/wino_ab.sh): 48->48 at 128x64^2 132.9 ->
+            // 128.3 us; the same order on the 96-channel kernel (256 VGPRs, no room for the second operand set) is
+            // neutral to 1 % slower, as are "position 0 first" and an MFMA / LDS / VALU interleave by
+            // sched_group_barrier (445 -> 467 us) — its K loop is not bound by instruction order.
+            loadb(b0, IC<P>{}, IC<0>{});
+            loadb(b1, IC<P>{}, IC<1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfma12(aop[P], b0, IC<0>{}, first);
+            __builtin_amdgcn_sched_barrier(0);
+            loadb(b0, IC<P>{}, IC<2>{});
+            transform(IC<1 - P>{}, aop[1 - P]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma12(aop[P], b1, IC<1>{}, first);
+            __builtin_amdgcn_sched_barrier(0);
+            loadb(b1, IC<P>{}, IC<3>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfma12(aop[P], b0, IC<2>{}, first);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma12(aop[P], b1, IC<3>{}, first);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
     for (;;) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[p][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < nch; c += 2) {
-            iter(IC<0>{}, c);
-            if (c + 1 < nch) iter(IC<1>{}, c + 1);
+        iter(IC<0>{}, 0, IC<1>{});
+        if (1 < nch) iter(IC<1>{}, 1, IC<0>{});
+        for (int c = 2; c < nch; c += 2) {
+            iter(IC<0>{}, c, IC<0>{});
+            if (c + 1 < nch) iter(IC<1>{}, c + 1, IC<0>{});
         }
         // The stages are free again: start the next tile's first loads now, under this tile's output transform.
         const int e_n = n, e_by = by, e_bx = bx;
@@ -288,8 +345,12 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     // tile' = lq + 4 r + 16 (T >> 4) with 4 lq + r = T & 15
     const int rl_tx = lane & ((1 << LGTX) - 1), rl_ty = lane >> LGTX;
     const int tprime = ((lane & 15) >> 2) + 4 * (lane & 3) + 16 * (lane >> 4);
-    const int oy = e_by * TR + 2 * rl_ty, ox = e_bx * TC + 2 * rl_tx;
+    // stores: a wave-uniform plane pointer (scalar arithmetic) + the lane's fixed byte offset inside the tile
+    const int lane_off = a.up2 ? ((4 * rl_ty) * (2 * a.W) + 4 * rl_tx) * 4 : ((2 * rl_ty) * a.W + 2 * rl_tx) * 4;
+    const long tile_org = a.up2 ? ((long)(2 * e_by * TR) * (2 * a.W) + 2 * e_bx * TC) : ((long)(e_by * TR) * a.W + e_bx * TC);
+    const long plane = a.up2 ? 4 * HW : HW;
     constexpr int PASSES = (NT + 1) / 2;
+    if (!(a.diag & 1))
 #pragma unroll
     for (int pass = 0; pass < PASSES; ++pass) {
 #pragma unroll
@@ -316,19 +377,20 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
             const int cp = wave + 8 * it;   // channel within the pass
             const int co = grp * (NT * 16) + pass * 32 + cp;
             if (pass * 32 + cp < NT * 16 && co < a.Cout) {
+                // mask of a fused activation backward: the saved activations at the output positions, fetched first
+                f32x2 mk0 = {1.f, 1.f}, mk1 = {1.f, 1.f};
+                if (a.mask) {
+                    const rsrc_t mr = make_rsrc(uniform_ptr(a.mask + ((long)e_n * a.Cout + co) * plane + tile_org));
+                    mk0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mr, lane_off, 0, 0));
+                    mk1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mr, lane_off, 4 * a.W, 0));
+                }
                 f32x2 s[4];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     s[w][0] = E[((w * 2 + 0) * 32 + cp) * ETS + tprime];
                     s[w][1] = E[((w * 2 + 1) * 32 + cp) * ETS + tprime];
                 }
-                float sc = 1.f, sh = 0.f;
-                if (a.scale) {
-                    sc = a.scale[co];
-                    sh = a.shift[co];
-                } else if (a.bias) {
-                    sh = a.bias[co];
-                }
+                const float sc = EC[pass * 32 + cp], sh = EC[96 + pass * 32 + cp];
                 f32x2 o0 = ((s[0] + s[1]) + s[2]) * sc + sh;
                 f32x2 o1 = ((s[1] - s[2]) - s[3]) * sc + sh;
                 if (a.act == SPRK_ACT_LEAKY) {   // max(v, 0.1 v) = v > 0 ? v : 0.1 v
@@ -338,18 +400,27 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
                     o0 = __builtin_elementwise_max(o0, (f32x2){0.f, 0.f});
                     o1 = __builtin_elementwise_max(o1, (f32x2){0.f, 0.f});
                 }
+                if (a.mask) {
+                    const float neg = a.mact == SPRK_ACT_LEAKY ? kLeak : 0.f;
+                    o0[0] *= mk0[0] > 0.f ? 1.f : neg;
+                    o0[1] *= mk0[1] > 0.f ? 1.f : neg;
+                    o1[0] *= mk1[0] > 0.f ? 1.f : neg;
+                    o1[1] *= mk1[1] > 0.f ? 1.f : neg;
+                }
+                // buffer stores: wave-uniform descriptor (plane + tile origin, scalar arithmetic), the lane's fixed byte
+                // offset, the row stride in the scalar offset — no vector address arithmetic in the epilogue
+                const rsrc_t yr = make_rsrc(uniform_ptr(a.y + ((long)e_n * a.Cout + co) * plane + tile_org));
                 if (a.up2) {   // nearest x2 upsampling fused into the stores: each value to its 2x2 block
-                    const int W2 = 2 * a.W;
-                    float *yp = a.y + (((long)e_n * a.Cout + co) * (2 * a.H) + 2 * oy) * W2 + 2 * ox;
-                    const f32x4 r0 = {o0[0], o0[0], o0[1], o0[1]}, r1 = {o1[0], o1[0], o1[1], o1[1]};
-                    *reinterpret_cast<f32x4 *>(yp) = r0;
-                    *reinterpret_cast<f32x4 *>(yp + W2) = r0;
-                    *reinterpret_cast<f32x4 *>(yp + 2 * W2) = r1;
-                    *reinterpret_cast<f32x4 *>(yp + 3 * W2) = r1;
+                    const int W2b = 8 * a.W;
+                    const u32x4 r0 = {fbits(o0[0]), fbits(o0[0]), fbits(o0[1]), fbits(o0[1])},
+                                r1 = {fbits(o1[0]), fbits(o1[0]), fbits(o1[1]), fbits(o1[1])};
+                    __builtin_amdgcn_raw_buffer_store_b128(r0, yr, lane_off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(r0, yr, lane_off, W2b, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(r1, yr, lane_off, 2 * W2b, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(r1, yr, lane_off, 3 * W2b, 0);
                 } else {
-                    float *yp = a.y + (((long)e_n * a.Cout + co) * a.H + oy) * a.W + ox;
-                    *reinterpret_cast<f32x2 *>(yp) = o0;
-                    *reinterpret_cast<f32x2 *>(yp + a.W) = o1;
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){fbits(o0[0]), fbits(o0[1])}, yr, lane_off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){fbits(o1[0]), fbits(o1[1])}, yr, lane_off, 4 * a.W, 0);
                 }
             }
         }
@@ -388,7 +459,7 @@ constexpr size_t kWgLdsBytes = (size_t)(2 * WSTAGE + 8 * kThreads) * 4;   // two
 struct WgKArgs {
     const float *x, *gy;
     float *partial;         // [parts][Cout][CinTot][9]
-    int N, Csrc, cbase, ci0, CinTot, H, W, Cout, padT, padL, regionsX, regionsY;   // cbase: first channel of group 0
+    int N, Csrc, cbase, ci0, CinTot, H, W, Cout, padT, padL, regionsX, regionsY, xcd;   // cbase: first channel of group 0
 };
 
 template <int MT>
@@ -519,7 +590,7 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a
         kstep(stage, IC<3>{});
     };
 
-    int region = blockIdx.x;
+    int region = xcd_slot(blockIdx.x, gridDim.x, a.xcd);
     if (region < nregions) issue(region, smem);
     for (; region < nregions; region += 2 * gridDim.x) {
         stage_body(IC<0>{}, region);
@@ -632,6 +703,11 @@ int wino_conv(const WinoArgs &w, hipStream_t s) {
     a.N = w.N; a.C1 = w.C1; a.C2 = w.C2; a.H = w.H; a.W = w.W; a.Cout = w.Cout; a.padT = w.padT; a.padL = w.padL;
     a.act = w.act;
     a.up2 = w.up2;
+    a.mask = w.up2 ? nullptr : w.mask;
+    a.mact = w.mask_act;
+    a.xcd = xcd_on();
+    static const int diag = getenv("SPRK_WINO_DIAG") ? atoi(getenv("SPRK_WINO_DIAG")) : 0;   // timing experiments only
+    a.diag = diag;
     const int sq = wino_square(w.H, w.W);
     a.tilesX = w.W / (sq ? Geo<1>::TC : Geo<0>::TC); a.tilesY = w.H / (sq ? Geo<1>::TR : Geo<0>::TR);
     a.ntiles = a.tilesX * a.tilesY * w.N;
@@ -711,7 +787,7 @@ int wino_wgrad(const WinoWgArgs &w, hipStream_t s) {
     auto launch = [&](const float *src, int Csrc, int ci0) -> int {
         int g48, tail;
         wg_split(Csrc, &g48, &tail);
-        WgKArgs a{src, w.gy, w.partial, w.N, Csrc, 0, ci0, CinTot, w.H, w.W, w.Cout, w.padT, w.padL, w.W / WRW, w.H / WRH};
+        WgKArgs a{src, w.gy, w.partial, w.N, Csrc, 0, ci0, CinTot, w.H, w.W, w.Cout, w.padT, w.padL, w.W / WRW, w.H / WRH, xcd_on()};
         if (g48 > 0) {
             if (!attr3) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_wgrad_kernel<3>),

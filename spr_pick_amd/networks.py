@@ -70,14 +70,15 @@ class Conv2d(nn.Module):
         p = self.padding
         return (p, p, p, p)
 
-    def forward(self, x, skip=None, up=False, up_out=False):
+    def forward(self, x, skip=None, up=False, up_out=False, x_act=ACT_NONE, premasked=False):
         """skip: second input source (channel concat); up: x is half resolution, upsampled on load;
-        up_out: write the output nearest-upsampled x2 (the nn.Upsample that follows in the reference)."""
+        up_out: write the output nearest-upsampled x2 (the nn.Upsample that follows in the reference);
+        x_act / premasked: activation backward fused into the neighbouring operators (ops.conv2d)."""
         # inference (no autograd): the kernel choice is pinned to the layer's structure (_lib.DT_PIN), so that a window
         # of a micrograph gets the very arithmetic the whole micrograph gets (Denoiser._tiled_networks)
         dtype = self.mfma_dtype if torch.is_grad_enabled() else (self.mfma_dtype | DT_PIN)
         return ops.conv2d(x, self.weight, self.bias, x2=skip, up1=up, stride=self.stride, dil=self.dilation,
-                          pad=self._pad(), act=self.act, up_out=up_out, dtype=dtype)
+                          pad=self._pad(), act=self.act, up_out=up_out, dtype=dtype, x_act=x_act, premasked=premasked)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%d, padding=%d, dilation=%d, act=%d%s" % (
@@ -115,8 +116,11 @@ class ShiftMaxPool(nn.Module):
         super().__init__()
         self.shift = shift
 
-    def forward(self, x):
-        return ops.shift_maxpool2(x, self.shift)
+    def forward(self, x, x_act=ACT_NONE):
+        return ops.shift_maxpool2(x, self.shift, x_act)
+
+
+FUSE_ACT_BWD = True     # debug: False = every convolution runs its own activation-backward pass
 
 
 def _kaiming_leaky(mod):
@@ -155,9 +159,24 @@ class _UNetBase(nn.Module):
         return nn.Sequential(*mods)
 
     @staticmethod
-    def _run_pool(block, t):
+    def _run_pool(block, t, x_act=ACT_NONE):
         p = block[-1]
-        return (p[1] if isinstance(p, nn.Sequential) else p)(t)
+        return (p[1] if isinstance(p, nn.Sequential) else p)(t, x_act)
+
+    # Activation backward fused into the neighbours (ops.conv2d: premasked / x_act).  Every conv -> conv and conv -> pool
+    # link of the U-Nets qualifies (the intermediate tensor has exactly one consumer); the convolution side is taken
+    # where the consumer's backward-data kernel applies the mask in its epilogue.
+    def _chain(self, first, second, x, skip=None, up_out=False):
+        """second(first(x, skip)): the LeakyReLU backward of `first` runs inside `second`'s backward-data kernel."""
+        fuse = torch.is_grad_enabled() and FUSE_ACT_BWD and first.act != ACT_NONE and second.kernel_size[0] == 3 \
+            and second.mfma_dtype == 0
+        t = first(x, skip=skip, premasked=fuse)
+        return second(t, up_out=up_out, x_act=first.act if fuse else ACT_NONE)
+
+    def _conv_pool(self, conv, block, x):
+        """pool(conv(x)): the LeakyReLU backward of `conv` runs inside the pooling backward."""
+        fuse = torch.is_grad_enabled() and FUSE_ACT_BWD and conv.act != ACT_NONE
+        return self._run_pool(block, conv(x, premasked=fuse), conv.act if fuse else ACT_NONE)
 
     @property
     def blindspot(self):
@@ -228,17 +247,21 @@ class DualNetwork(_UNetBase):
             x = ops.rot4_stack(x)
         e1, e2, e3, e4, e5, e6 = (self.encode_block_1, self.encode_block_2, self.encode_block_3, self.encode_block_4,
                                   self.encode_block_5, self.encode_block_6)
-        pool1 = self._run_pool(e1, e1[2](e1[0](x)))
-        pool2 = self._run_pool(e2, e2[0](pool1))
-        pool3 = self._run_pool(e3, e3[0](pool2))
-        pool4 = self._run_pool(e4, e4[0](pool3))
-        pool5 = self._run_pool(e5, e5[0](pool4))
+        fuse = torch.is_grad_enabled() and FUSE_ACT_BWD
+        t = e1[0](x, premasked=fuse and e1[2].mfma_dtype == 0)
+        # encode_block_1 is conv -> conv -> pool
+        t = e1[2](t, x_act=ACT_LEAKY if fuse and e1[2].mfma_dtype == 0 else ACT_NONE, premasked=fuse)
+        pool1 = self._run_pool(e1, t, ACT_LEAKY if fuse else ACT_NONE)
+        pool2 = self._conv_pool(e2[0], e2, pool1)
+        pool3 = self._conv_pool(e3[0], e3, pool2)
+        pool4 = self._conv_pool(e4[0], e4, pool3)
+        pool5 = self._conv_pool(e5[0], e5, pool4)
         # every nn.Upsample of the reference is fused into the stores of the conv that feeds it
         t = e6[0](pool5, up_out=True)
         for blk, skip, up_out in ((self.decode_block_5, pool4, True), (self.decode_block_4, pool3, True),
                                   (self.decode_block_3, pool2, True), (self.decode_block_2, pool1, True),
                                   (self.decode_block_1, x, False)):
-            t = blk[2](blk[0](t, skip=skip), up_out=up_out)
+            t = self._chain(blk[0], blk[2], t, skip=skip, up_out=up_out)
         if self._blindspot:
             t = ops.unrot4_shift_concat(t)
         t = self.output_block[2](self.output_block[0](t))
@@ -288,13 +311,16 @@ class DualNetworkShallow(_UNetBase):
             raise NotImplementedError("DualNetworkShallow(blindspot=True) is not on the joint pipeline's path "
                                       "(reference: denoiser_v2.py:129-137 always passes blindspot=False)")
         e1, e2, e3, e6 = self.encode_block_1, self.encode_block_2, self.encode_block_3, self.encode_block_6
-        pool1 = self._run_pool(e1, e1[2](e1[0](x)))
-        pool2 = self._run_pool(e2, e2[0](pool1))
-        pool3 = self._run_pool(e3, e3[0](pool2))
+        fuse = torch.is_grad_enabled() and FUSE_ACT_BWD
+        t = e1[0](x, premasked=fuse and e1[2].mfma_dtype == 0)
+        t = e1[2](t, x_act=ACT_LEAKY if fuse and e1[2].mfma_dtype == 0 else ACT_NONE, premasked=fuse)
+        pool1 = self._run_pool(e1, t, ACT_LEAKY if fuse else ACT_NONE)
+        pool2 = self._conv_pool(e2[0], e2, pool1)
+        pool3 = self._conv_pool(e3[0], e3, pool2)
         t = e6[0](pool3, up_out=True)
         for blk, skip, up_out in ((self.decode_block_5, pool2, True), (self.decode_block_2, pool1, True),
                                   (self.decode_block_1, x, False)):
-            t = blk[2](blk[0](t, skip=skip), up_out=up_out)
+            t = self._chain(blk[0], blk[2], t, skip=skip, up_out=up_out)
         t = self.output_block[2](self.output_block[0](t))
         return self.output_conv(t)
 

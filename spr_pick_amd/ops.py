@@ -114,7 +114,8 @@ def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None,
 
 class _Conv2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x2, w, bias, up1, stride, dil, pad, act, up_out, dtype):
+    def forward(ctx, x, x2, w, bias, up1, stride, dil, pad, act, up_out, dtype, x_act=ACT_NONE, premasked=False):
+        ctx.x_act, ctx.premasked = x_act, premasked
         x = x.contiguous()
         x2 = None if x2 is None else x2.contiguous()
         w = w.contiguous()
@@ -140,15 +141,20 @@ class _Conv2dFn(torch.autograd.Function):
         need_b = ctx.has_bias and ctx.needs_input_grad[3]
         # gradient w.r.t. the pre-activation output (+ bias gradient)
         up2 = 1 if ctx.up_out else 0
-        if ctx.act != ACT_NONE or need_b or up2:
-            want_gpre = ctx.act != ACT_NONE or bool(up2)
+        # premasked: the consumer of this layer's output (the next convolution's backward-data, or the pooling backward)
+        # has already multiplied the gradient by act'(y): only the bias sum is left of the activation backward
+        act_here = ACT_NONE if ctx.premasked else ctx.act
+        if act_here != ACT_NONE or need_b or up2:
+            want_gpre = act_here != ACT_NONE or bool(up2)
             defer_b = False
             if need_b:
                 gb, defer_b = _grad_dest(bias)
-            out = _S.act_bwd(gy, y, ctx.act, [g.N, g.Cout, g.Hout, g.Wout], up2, want_gpre, gb, defer_b)
+            if not want_gpre:
+                gy = gy.contiguous()
+            out = _S.act_bwd(gy, y, act_here, [g.N, g.Cout, g.Hout, g.Wout], up2, want_gpre, gb, defer_b)
             gpre = out if want_gpre else gy
         else:
-            gpre = gy
+            gpre = gy.contiguous()
         if ctx.needs_input_grad[2]:
             gw, defer_w = _grad_dest(w)
             _S.conv2d_bwd_weight(x, x2, gpre, geom_list(g), gw, defer_w)
@@ -174,7 +180,12 @@ class _Conv2dFn(torch.autograd.Function):
                 gsrc[:, :, ::st, ::st] = gpre
                 gd = ConvGeom(gd.N, gd.C1, gd.C2, gd.Hin, gd.Win, gd.up1, gd.Cout, H1, W1, gd.KH, gd.KW, 1, gd.dil,
                               gd.pad_top, gd.pad_left, gd.dtype)
-            gin = _S.conv2d_bwd_data(gsrc, wd, geom_list(gd))
+            # x_act: x is the output of an activated layer that this convolution alone consumes — its activation
+            # backward is fused into this backward-data call (the saved input is the mask)
+            masked = ctx.x_act != ACT_NONE and gd.C2 == 0 and not gd.up1
+            gin = _S.conv2d_bwd_data(gsrc, wd, geom_list(gd), x if masked else None, ctx.x_act if masked else ACT_NONE)
+            if ctx.x_act != ACT_NONE and not masked:
+                raise _lib.SprkError("conv2d: x_act needs a single, full-resolution input source")
             if gd.C2 == 0 and not gd.up1:
                 gx = gin
             elif not gd.up1:
@@ -185,40 +196,47 @@ class _Conv2dFn(torch.autograd.Function):
                 gx, gx2 = _S.concat_up_bwd(gin, gd.C1, gd.C2, gd.up1, list(x.shape), list(x2.shape) if gd.C2 else [0])
                 if not gd.C2:
                     gx2 = None
-        return gx, gx2, gw, gb, None, None, None, None, None, None, None
+        return gx, gx2, gw, gb, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, bias=None, x2=None, up1=False, stride=1, dil=1, pad=(0, 0, 0, 0), act=ACT_NONE, up_out=False,
-           dtype=0):
+           dtype=0, x_act=ACT_NONE, premasked=False):
     """y = act(conv(cat(up2(x) if up1 else x, x2), w) + bias); pad = (top, bottom, left, right).
     up_out: return nearest-x2-upsampled y (the upsampling is fused into the conv's stores).
     dtype: _lib.DT_F32 / DT_BF16 / DT_F16 — precision of the MFMA operands in forward, backward-data and
-    backward-weight (a request: layers without a 16-bit kernel run in fp32; tensors are fp32 either way)."""
+    backward-weight (a request: layers without a 16-bit kernel run in fp32; tensors are fp32 either way).
+    Activation backward fused into the neighbours (conv -> conv and conv -> pool chains; a pair of promises the CALLER
+    makes, networks.py): ``premasked`` — this layer's output is consumed by exactly one operator, which was told so
+    (``x_act``) and returns the gradient already multiplied by act'(y); ``x_act`` — x is such an output."""
     _need_gpu(x, x2, w, bias)
+    if premasked and (up_out or act == ACT_NONE):
+        raise ValueError("conv2d: premasked needs an activated, not upsampled output")
     return _Conv2dFn.apply(x, x2, w, bias, bool(up1), int(stride), int(dil), tuple(int(p) for p in pad), int(act),
-                           bool(up_out), int(dtype))
+                           bool(up_out), int(dtype), int(x_act), bool(premasked))
 
 
 # ---- U-Net plumbing -----------------------------------------------------------------------------
 class _ShiftMaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, shift):
+    def forward(ctx, x, shift, x_act):
         x = x.contiguous()
         _need_gpu(x)
         if x.shape[2] % 2 or x.shape[3] % 2:
             raise ValueError("shift_maxpool2: odd spatial size %dx%d" % (x.shape[2], x.shape[3]))
-        ctx.shift = shift
+        ctx.shift, ctx.x_act = shift, x_act
         ctx.save_for_backward(x)
         return _S.shift_maxpool2_fwd(x, shift)
 
     @staticmethod
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
-        return _S.shift_maxpool2_bwd(gy.contiguous(), x, ctx.shift), None
+        return _S.shift_maxpool2_bwd(gy.contiguous(), x, ctx.shift, ctx.x_act), None, None
 
 
-def shift_maxpool2(x, shift=1):
-    return _ShiftMaxPoolFn.apply(x, int(shift))
+def shift_maxpool2(x, shift=1, x_act=ACT_NONE):
+    """x_act: x is the output of an activated convolution (called with premasked=True) that only this pool consumes:
+    the gradient is returned multiplied by act'(x)."""
+    return _ShiftMaxPoolFn.apply(x, int(shift), int(x_act))
 
 
 class _Rot4Fn(torch.autograd.Function):

@@ -77,18 +77,23 @@ _register("conv2d_fwd", "(Tensor x, Tensor? x2, Tensor w, Tensor? bias, Tensor? 
                         "int[] geom, int res_off, int act, int up_out) -> Tensor", _conv2d_fwd, _conv2d_fwd_fake)
 
 
-def _conv2d_bwd_data(gy, w, geom):
+def _conv2d_bwd_data(gy, w, geom, mask_y, mask_act):
+    """mask_y / mask_act: fuse the activation backward of the layer that produced this convolution's input (the saved
+    input itself is the mask): the result is that layer's pre-activation gradient (sprk_conv2d_bwd_data_masked)."""
     L = _lib.lib()
     g = ConvGeom(*geom)
     gin = _f32(gy, (g.N, g.C1 + g.C2, g.Hin, g.Win))
     nb = L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(g))
     ws = _ws(nb, gy)
-    check(L.sprk_conv2d_bwd_data(_p(gy), _p(w), _p(gin), ctypes.byref(g), _p(ws), nb, _stream(gy)), "sprk_conv2d_bwd_data")
+    if mask_y is not None and tuple(mask_y.shape) != tuple(gin.shape):
+        raise _lib.SprkError("conv2d_bwd_data: mask %s does not match the input gradient %s" % (tuple(mask_y.shape), tuple(gin.shape)))
+    check(L.sprk_conv2d_bwd_data_masked(_p(gy), _p(w), _p(gin), ctypes.byref(g), _p(mask_y), int(mask_act) if mask_y is not None else 0,
+                                        _p(ws), nb, _stream(gy)), "sprk_conv2d_bwd_data_masked")
     return gin
 
 
-_register("conv2d_bwd_data", "(Tensor gy, Tensor w, int[] geom) -> Tensor", _conv2d_bwd_data,
-          lambda gy, w, geom: gy.new_empty((geom[0], geom[1] + geom[2], geom[3], geom[4])))
+_register("conv2d_bwd_data", "(Tensor gy, Tensor w, int[] geom, Tensor? mask_y, int mask_act) -> Tensor", _conv2d_bwd_data,
+          lambda gy, w, geom, mask_y, mask_act: gy.new_empty((geom[0], geom[1] + geom[2], geom[3], geom[4])))
 
 
 # Pending second-stage sums (sprk_reduce_items): with defer=True the backward-weight / bias-gradient operators run only
@@ -204,9 +209,9 @@ def _simple(name, schema, cfn, out_shape, args):
 _simple("shift_maxpool2_fwd", "(Tensor x, int shift) -> Tensor", "sprk_shift_maxpool2_fwd",
         lambda x, shift: (x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2),
         lambda a, y: (_p(a[0]), _p(y), a[0].shape[0] * a[0].shape[1], a[0].shape[2], a[0].shape[3], a[1]))
-_simple("shift_maxpool2_bwd", "(Tensor gy, Tensor x, int shift) -> Tensor", "sprk_shift_maxpool2_bwd",
-        lambda gy, x, shift: tuple(x.shape),
-        lambda a, y: (_p(a[0]), _p(a[1]), _p(y), a[1].shape[0] * a[1].shape[1], a[1].shape[2], a[1].shape[3], a[2]))
+_simple("shift_maxpool2_bwd", "(Tensor gy, Tensor x, int shift, int act) -> Tensor", "sprk_shift_maxpool2_bwd",
+        lambda gy, x, shift, act: tuple(x.shape),
+        lambda a, y: (_p(a[0]), _p(a[1]), _p(y), a[1].shape[0] * a[1].shape[1], a[1].shape[2], a[1].shape[3], a[2], a[3]))
 _simple("rot4_stack_fwd", "(Tensor x) -> Tensor", "sprk_rot4_stack_fwd",
         lambda x: (4 * x.shape[0], x.shape[1], x.shape[2], x.shape[3]),
         lambda a, y: (_p(a[0]), _p(y), a[0].shape[0], a[0].shape[1], a[0].shape[2]))
