@@ -135,6 +135,27 @@ int sprk_conv2d_bwd_data_masked(const float *gy, const float *w, float *gin, con
 size_t sprk_conv2d_bwd_weight_ws_bytes(const sprk_conv_geom *g);
 int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, float *gw,
                            const sprk_conv_geom *g, void *ws, size_t ws_bytes, void *stream);
+/* ---- prepared weights: one launch per training step instead of one per convolution call ------------------------
+ * Every convolution call re-lays its weights out in its workspace before the main kernel (k-chunked slabs, Winograd
+ * G g G^T, 16-bit slabs): ~100 small launches per training step, 2-3 % of it.  A caller whose weights change once per
+ * step (an optimiser) can hoist them:
+ *   1. once per layer and direction, with a workspace that it KEEPS: sprk_conv2d_fwd_wprep / _bwd_data_wprep describe
+ *      the transform that call would run (no launch; item->kind == 0: that path has none);
+ *   2. after every weight update: sprk_prepare_weights(items, n) — all transforms in one launch per 40 items;
+ *   3. the convolution calls pass the same workspace and SPRK_DT_WPREP in dtype: the transform launch is skipped.
+ * Same device code either way: results are bit-identical to the plain calls.  The items are opaque. */
+#define SPRK_DT_WPREP 0x800
+typedef struct sprk_wprep_item {
+    const float *w;
+    void *dst;
+    int32_t kind, blocks;
+    int32_t p[12];
+} sprk_wprep_item;
+int sprk_conv2d_fwd_wprep(const float *w, const sprk_conv_geom *g, const sprk_conv_epilogue *ep, void *ws,
+                          size_t ws_bytes, sprk_wprep_item *item);
+int sprk_conv2d_bwd_data_wprep(const float *w, const sprk_conv_geom *g, void *ws, size_t ws_bytes, sprk_wprep_item *item);
+int sprk_prepare_weights(const sprk_wprep_item *items, int n, void *stream);
+
 /* gpre[N,C,H,W] = gy * act'(y) where y is the saved POST-activation output (gpre may alias gy;
  * with act == NONE and up2 == 0 nothing is written to gpre and it may be NULL); if gbias != NULL
  * also gbias[c] = sum over n,h,w of gpre (conv bias gradient).  up2 != 0: gy and y are the

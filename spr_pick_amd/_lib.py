@@ -9,6 +9,7 @@ LIB_PATH = os.environ.get("SPRK_LIB") or os.path.join(_HERE, "libsprk.so")   # S
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2          # SPRK_DT_*: precision of the MFMA operands (include/sprk.h)
 DT_NAIVE = 0x200                           # SPRK_DT_NAIVE: plain per-output-element kernels for this call (cross-check)
+DT_WPREP = 0x800                           # SPRK_DT_WPREP: the workspace already holds the transformed weights
 DT_PIN = 0x400                             # SPRK_DT_PIN: kernel choice by layer structure only (inference: tiled == whole)
 DT_FORCE = 0x100                           # SPRK_DT_FORCE: 16-bit kernel wherever it exists (tests), not only where faster
 DTYPES = {"f32": DT_F32, "fp32": DT_F32, "bf16": DT_BF16, "f16": DT_F16, "fp16": DT_F16,
@@ -43,6 +44,11 @@ class ReduceItem(ctypes.Structure):
                 ("K", ctypes.c_int32), ("Cout", ctypes.c_int32), ("CoutP", ctypes.c_int32)]
 
 
+class WprepItem(ctypes.Structure):
+    """sprk_wprep_item: a weight transform as data (opaque; include/sprk.h)."""
+    _fields_ = [("w", c_vp), ("dst", c_vp), ("kind", ctypes.c_int32), ("blocks", ctypes.c_int32), ("p", ctypes.c_int32 * 12)]
+
+
 _SIGS = {
     "sprk_last_error": (ctypes.c_char_p, []),
     "sprk_version": (c_i, []),
@@ -53,6 +59,9 @@ _SIGS = {
     "sprk_wgrad16_launch_count": (ctypes.c_long, []),
     "sprk_conv2d_fwd_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_fwd": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue), c_vp, c_sz, c_vp]),
+    "sprk_conv2d_fwd_wprep": (c_i, [c_f, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue), c_vp, c_sz, ctypes.POINTER(WprepItem)]),
+    "sprk_conv2d_bwd_data_wprep": (c_i, [c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, ctypes.POINTER(WprepItem)]),
+    "sprk_prepare_weights": (c_i, [ctypes.POINTER(WprepItem), c_i, c_vp]),
     "sprk_conv2d_bwd_data_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_bwd_data": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_data_masked": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_f, c_i, c_vp, c_sz, c_vp]),
@@ -115,7 +124,7 @@ def lib():
         if L.sprk_version() != ABI_VERSION:
             raise SprkError("libsprk.so at %s has ABI version %d, this binding needs %d — rebuild it "
                             "(make -C spr_pick_amd/csrc)" % (LIB_PATH, L.sprk_version(), ABI_VERSION))
-        for which, st in enumerate((ConvGeom, ConvEpilogue, ReduceItem, AdamItem)):
+        for which, st in enumerate((ConvGeom, ConvEpilogue, ReduceItem, AdamItem, WprepItem)):
             if L.sprk_struct_bytes(which) != ctypes.sizeof(st):
                 raise SprkError("libsprk.so: sizeof(%s) is %d in the library, %d in the binding"
                                 % (st.__name__, L.sprk_struct_bytes(which), ctypes.sizeof(st)))

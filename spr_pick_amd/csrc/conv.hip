@@ -20,6 +20,7 @@
 #include "conv16.h"
 #include "wgrad16.h"
 #include "wino.h"
+#include "wprep_dev.h"
 
 #include <cstdlib>
 
@@ -46,35 +47,6 @@ constexpr int kClass16W = 6;  // ... of the 16-bit-operand backward-weight kerne
 // ------------------------------------------------------------------------------------------
 constexpr int kZeroFloats = 256;
 __device__ __attribute__((aligned(64))) float g_zero_block[kZeroFloats];  // zero-initialised; source of out-of-image DMA lanes
-
-__global__ void weight_transform_kernel(const float *__restrict__ w, float *__restrict__ ws, int Cout, int Cin,
-                                        int KHW, int mode, int CK, int R4, int rows, int NT16, int ldw, int nblk) {
-    const int Ck = mode == 0 ? Cin : Cout;   // channels along GEMM-k
-    const int Nn = mode == 0 ? Cout : Cin;   // GEMM-n extent
-    const long total = (long)nblk * rows * ldw + kZeroFloats;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        float v = 0.f;
-        if (e >= kZeroFloats) {
-            long t = e - kZeroFloats;
-            const int col = (int)(t % ldw);
-            t /= ldw;
-            const int row = (int)(t % rows);
-            const int nb = (int)(t / rows);
-            const int n = nb * NT16 + col;
-            const int q = row / R4, rr = row - q * R4;
-            const int cke = min(CK, Ck - q * CK);
-            if (col < NT16 && n < Nn && rr < cke * KHW) {
-                const int tap = rr / cke, cl = rr - tap * cke;
-                const int ck = q * CK + cl;
-                if (mode == 0)
-                    v = w[((long)n * Cin + ck) * KHW + tap];
-                else
-                    v = w[((long)ck * Cin + n) * KHW + (KHW - 1 - tap)];
-            }
-        }
-        ws[e] = v;
-    }
-}
 
 // nch channel planes from one source tensor: `base` points at channel 0 of image 0 of the staged
 // channel range; imgStride / cs are the image / channel strides in floats; (Hs, Ws) the source plane
@@ -1149,9 +1121,8 @@ void fill_args(ConvArgs &a, const FwdPlan &p) {
 int transform_weights(const float *w, float *ws, int Cout, int Cin, int KHW, int mode, const FwdPlan &p,
                       hipStream_t s) {
     const long total = (long)p.nblkN * p.rows * p.ldw + kZeroFloats;
-    hipLaunchKernelGGL(weight_transform_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, s, w, ws, Cout, Cin, KHW,
-                       mode, p.CK, p.R4, p.rows, p.NT * 16, p.ldw, p.nblkN);
-    return sprk::check_launch("weight_transform");
+    return sprk::wprep_site(sprk::wprep_item(sprk::WPREP_DIRECT, w, ws, total,
+                                             {Cout, Cin, KHW, mode, p.CK, p.R4, p.rows, p.NT * 16, p.ldw, p.nblkN}), s);
 }
 
 int check_geom(const sprk_conv_geom *g) {
@@ -1372,8 +1343,28 @@ size_t sprk_conv2d_fwd_ws_bytes(const sprk_conv_geom *g) {
     return need;
 }
 
+static int conv2d_fwd_impl(const float *x, const float *x2, const float *w, float *y, const sprk_conv_geom *g,
+                           const sprk_conv_epilogue *ep, void *ws, size_t ws_bytes, void *stream);
+
 int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, const sprk_conv_geom *g,
                     const sprk_conv_epilogue *ep, void *ws, size_t ws_bytes, void *stream) {
+    sprk::WprepScope scope(nullptr, g && (g->dtype & SPRK_DT_WPREP));
+    return conv2d_fwd_impl(x, x2, w, y, g, ep, ws, ws_bytes, stream);
+}
+
+int sprk_conv2d_fwd_wprep(const float *w, const sprk_conv_geom *g, const sprk_conv_epilogue *ep, void *ws,
+                          size_t ws_bytes, sprk_wprep_item *item) {
+    SPRK_REQUIRE(item && w && ws, "conv2d_fwd_wprep: null argument");
+    *item = sprk_wprep_item{};
+    sprk::WprepScope scope(item, false);
+    // the tensors are never touched in describe mode: the call ends at its weight-transform site
+    const float *dummy = (const float *)ws;
+    const int rc = conv2d_fwd_impl(dummy, g && g->C2 ? dummy : nullptr, w, (float *)ws, g, ep, ws, ws_bytes, nullptr);
+    return rc == sprk::kWprepDescribed ? (int)SPRK_OK : rc;
+}
+
+static int conv2d_fwd_impl(const float *x, const float *x2, const float *w, float *y, const sprk_conv_geom *g,
+                           const sprk_conv_epilogue *ep, void *ws, size_t ws_bytes, void *stream) {
     if (int rc = check_geom(g)) return rc;
     SPRK_REQUIRE(x && w && y, "conv2d_fwd: null tensor");
     SPRK_REQUIRE(g->C2 == 0 || x2, "conv2d_fwd: C2 > 0 but x2 is null");
@@ -1382,6 +1373,7 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, c
     if (!ep) ep = &e0;
     SPRK_REQUIRE(!ep->scale || ep->shift, "conv2d_fwd: scale without shift");
     if (naive_of(g)) {
+        if (sprk::wprep_describing()) return SPRK_OK;   // no weight transform on this path
         DirectArgs a{x, x2, w, nullptr, y, *g, *ep};
         const long total = (long)g->N * g->Cout * g->Hout * g->Wout;
         hipLaunchKernelGGL(conv_fwd_direct_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, s, a);
@@ -1455,7 +1447,24 @@ static int mask_in_place(float *gin, const float *mask_y, int mask_act, const sp
     return sprk_act_bwd(gin, mask_y, gin, nullptr, mask_act, g->N, g->C1 + g->C2, g->Hin, g->Win, 0, 0, nullptr, 0, s);
 }
 
+static int conv2d_bwd_data_impl(const float *gy, const float *w, float *gin, const sprk_conv_geom *g,
+                                const float *mask_y, int mask_act, void *ws, size_t ws_bytes, void *stream);
+
 int sprk_conv2d_bwd_data_masked(const float *gy, const float *w, float *gin, const sprk_conv_geom *g,
+                                const float *mask_y, int mask_act, void *ws, size_t ws_bytes, void *stream) {
+    sprk::WprepScope scope(nullptr, g && (g->dtype & SPRK_DT_WPREP));
+    return conv2d_bwd_data_impl(gy, w, gin, g, mask_y, mask_act, ws, ws_bytes, stream);
+}
+
+int sprk_conv2d_bwd_data_wprep(const float *w, const sprk_conv_geom *g, void *ws, size_t ws_bytes, sprk_wprep_item *item) {
+    SPRK_REQUIRE(item && w && ws, "conv2d_bwd_data_wprep: null argument");
+    *item = sprk_wprep_item{};
+    sprk::WprepScope scope(item, false);
+    const int rc = conv2d_bwd_data_impl((const float *)ws, w, (float *)ws, g, nullptr, SPRK_ACT_NONE, ws, ws_bytes, nullptr);
+    return rc == sprk::kWprepDescribed ? (int)SPRK_OK : rc;
+}
+
+static int conv2d_bwd_data_impl(const float *gy, const float *w, float *gin, const sprk_conv_geom *g,
                                 const float *mask_y, int mask_act, void *ws, size_t ws_bytes, void *stream) {
     if (int rc = check_geom(g)) return rc;
     SPRK_REQUIRE(gy && w && gin, "conv2d_bwd_data: null tensor");
@@ -1464,6 +1473,7 @@ int sprk_conv2d_bwd_data_masked(const float *gy, const float *w, float *gin, con
     hipStream_t s = (hipStream_t)stream;
     const int Cin = g->C1 + g->C2;
     if (naive_of(g) || g->stride != 1) {
+        if (sprk::wprep_describing()) return SPRK_OK;   // no weight transform on this path
         sprk_conv_epilogue e0 = {nullptr, nullptr, nullptr, nullptr, 0, 0, 0, SPRK_ACT_NONE, 0};
         DirectArgs a{nullptr, nullptr, w, gy, gin, *g, e0};
         const long total = (long)g->N * Cin * g->Hin * g->Win;

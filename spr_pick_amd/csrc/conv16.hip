@@ -21,6 +21,7 @@
 //     odd channel in a group of its own whose other 7 slots carry zero weights and re-read the same plane.
 // Epilogue (bias / BN affine / activation / fused 2x upsampling store) is conv_dev.h's, shared with the fp32 kernel.
 #include "conv16.h"
+#include "wprep_dev.h"
 
 #include "conv_dev.h"
 
@@ -60,38 +61,11 @@ struct Conv16Args {
     int diag;            // debug bits (SPRK_C16_DIAG): 1 no input DMA, 2 no weight DMA, 4 no MFMA loop, 8 no store
 };
 
-// ---- weights: fp32 [Cout][Cin][KHW] -> 16-bit slabs -------------------------------------------------------
-//   mode 0 (forward):        GEMM-k channel = cin,  n = cout, tap as is
-//   mode 1 (backward-data):  GEMM-k channel = cout, n = cin,  tap flipped
-template <typename T>
-__global__ void weight_transform16_kernel(const float *__restrict__ w, T *__restrict__ ws, int Cout, int Cin, int KHW,
-                                          int mode, int CK, int G4, int NT16, int nblk, int nchunks) {
-    const int Ck = mode == 0 ? Cin : Cout;
-    const int Nn = mode == 0 ? Cout : Cin;
-    const long total = (long)nblk * nchunks * G4 * NT16 * 8;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        long t = e;
-        const int j = (int)(t & 7);
-        t >>= 3;
-        const int nl = (int)(t % NT16);
-        t /= NT16;
-        const int G = (int)(t % G4);
-        t /= G4;
-        const int q = (int)(t % nchunks);
-        const int nb = (int)(t / nchunks);
-        const int cke = min(CK, Ck - q * CK), c8 = (cke + 7) >> 3;
-        const int n = nb * NT16 + nl;
-        float v = 0.f;
-        if (G < KHW * c8 && n < Nn) {
-            const int tap = G / c8, cg = G - tap * c8;
-            const int cl = cg * 8 + j;
-            if (cl < cke) {
-                const int ck = q * CK + cl;
-                v = mode == 0 ? w[((long)n * Cin + ck) * KHW + tap] : w[((long)ck * Cin + n) * KHW + (KHW - 1 - tap)];
-            }
-        }
-        ws[e] = (T)v;
-    }
+// ---- weights: fp32 [Cout][Cin][KHW] -> 16-bit slabs: a prepared-weight item (wprep_dev.h: wprep_16) ----------------
+static int transform16(const sprk::Conv16Call &c, const float *w, void *ws, long total, int wCout, int wCin, int KHW,
+                       int CK, int G4, int NT16, int nblk, int nchunks, hipStream_t s) {
+    const int kind = (c.dtype & SPRK_DT_MASK) == SPRK_DT_BF16 ? sprk::WPREP_BF16 : sprk::WPREP_F16;
+    return sprk::wprep_site(sprk::wprep_item(kind, w, ws, total, {wCout, wCin, KHW, c.mode, CK, G4, NT16, nblk, nchunks}), s);
 }
 
 // ---- one staged chunk: nks k-steps of 32 ---------------------------------------------------------------------
@@ -892,13 +866,7 @@ static int run_tile(const Conv16Call &c, const PlanT &p, const float *x, const f
     const int dt = c.dtype & SPRK_DT_MASK;
     const long total = (long)p.nblkN * p.nchunks * p.G4 * p.NT * 16 * 8;
     const int wCout = c.mode == 0 ? c.Cout : Cin, wCin = c.mode == 0 ? Cin : c.Cout;
-    if (dt == SPRK_DT_BF16)
-        hipLaunchKernelGGL(weight_transform16_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (__bf16 *)ws,
-                           wCout, wCin, 9, c.mode, kTileCK, p.G4, p.NT * 16, p.nblkN, p.nchunks);
-    else
-        hipLaunchKernelGGL(weight_transform16_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (_Float16 *)ws,
-                           wCout, wCin, 9, c.mode, kTileCK, p.G4, p.NT * 16, p.nblkN, p.nchunks);
-    if (int rc = check_launch("weight_transform16")) return rc;
+    if (int rc = transform16(c, w, ws, total, wCout, wCin, 9, kTileCK, p.G4, p.NT * 16, p.nblkN, p.nchunks, s)) return rc;
     Tile16Args k{};
     ConvArgs &a = k.c;
     a.x = x; a.x2 = x2; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift; a.res = nullptr; a.y = y;
@@ -940,13 +908,7 @@ static int run_head(const Conv16Call &c, const float *x, const float *w, float *
     const int dt = c.dtype & SPRK_DT_MASK;
     const long total = (long)nchunks * 8 * kHeadCoutP * 8;
     const int wCout = c.mode == 0 ? c.Cout : c.C1, wCin = c.mode == 0 ? c.C1 : c.Cout;
-    if (dt == SPRK_DT_BF16)
-        hipLaunchKernelGGL(weight_transform16_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (__bf16 *)ws,
-                           wCout, wCin, 1, c.mode, kHeadCK, 8, kHeadCoutP, 1, nchunks);
-    else
-        hipLaunchKernelGGL(weight_transform16_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (_Float16 *)ws,
-                           wCout, wCin, 1, c.mode, kHeadCK, 8, kHeadCoutP, 1, nchunks);
-    if (int rc = check_launch("weight_transform16")) return rc;
+    if (int rc = transform16(c, w, ws, total, wCout, wCin, 1, kHeadCK, 8, kHeadCoutP, 1, nchunks, s)) return rc;
     Head16Args a{};
     a.x = x; a.w16 = ws; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift; a.y = y;
     a.N = c.N; a.Cin = c.C1; a.Cout = c.Cout; a.HW = c.Hin * c.Win; a.act = c.act; a.nchunks = nchunks;
@@ -994,13 +956,7 @@ int conv16_run(const Conv16Call &c, const float *x, const float *x2, const float
     const long total = (long)p.nblkN * p.nchunks * p.G4 * p.NT * 16 * 8;
     const int wCout = c.mode == 0 ? c.Cout : Cin, wCin = c.mode == 0 ? Cin : c.Cout;
     const int dt = c.dtype & SPRK_DT_MASK;
-    if (dt == SPRK_DT_BF16)
-        hipLaunchKernelGGL(weight_transform16_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (__bf16 *)ws,
-                           wCout, wCin, KHW, c.mode, p.CK, p.G4, p.NT * 16, p.nblkN, p.nchunks);
-    else
-        hipLaunchKernelGGL(weight_transform16_kernel<_Float16>, dim3(ew_blocks(total)), dim3(256), 0, s, w, (_Float16 *)ws,
-                           wCout, wCin, KHW, c.mode, p.CK, p.G4, p.NT * 16, p.nblkN, p.nchunks);
-    if (int rc = check_launch("weight_transform16")) return rc;
+    if (int rc = transform16(c, w, ws, total, wCout, wCin, KHW, p.CK, p.G4, p.NT * 16, p.nblkN, p.nchunks, s)) return rc;
 
     Conv16Args k{};
     ConvArgs &a = k.c;

@@ -1,6 +1,7 @@
 // libsprk.so: error reporting, diagnostics and the event-based kernel timing used by
 // bench.py's roofline leg.
 #include "common.h"
+#include "wprep_dev.h"
 #include "conv16.h"
 #include "wgrad16.h"
 
@@ -144,9 +145,82 @@ int reduce_items(const sprk_reduce_item *items, int n, hipStream_t s) {
     return SPRK_OK;
 }
 
+// ---- prepared weights (wprep_dev.h) -------------------------------------------------------------------------------
+constexpr int kWprepMax = 40;   // items per launch: the table travels in the kernel argument (72 bytes each)
+struct WprepTable {
+    sprk_wprep_item it[kWprepMax];
+    int start[kWprepMax + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void wprep_kernel(const WprepTable t) {
+    const int b = blockIdx.x;
+    int i = 0;
+    while (i + 1 < t.n && b >= t.start[i + 1]) ++i;
+    const sprk_wprep_item &it = t.it[i];
+    const long first = (long)(b - t.start[i]) * 256 + threadIdx.x, stride = (long)(t.start[i + 1] - t.start[i]) * 256;
+    switch (it.kind) {
+        case WPREP_DIRECT: wprep_direct(it.w, (float *)it.dst, it.p, first, stride); break;
+        case WPREP_WINO: wprep_wino(it.w, (float *)it.dst, it.p, first, stride); break;
+        case WPREP_BF16: wprep_16<__bf16>(it.w, (__bf16 *)it.dst, it.p, first, stride); break;
+        case WPREP_F16: wprep_16<_Float16>(it.w, (_Float16 *)it.dst, it.p, first, stride); break;
+        default: break;
+    }
+}
+
+int wprep_launch(const sprk_wprep_item *items, int n, hipStream_t s) {
+    for (int base = 0; base < n; base += kWprepMax) {
+        WprepTable t;
+        t.n = 0;
+        int blocks = 0;
+        for (int i = base; i < n && i < base + kWprepMax; ++i) {
+            const sprk_wprep_item &it = items[i];
+            if (it.kind == WPREP_NONE) continue;
+            if (it.kind < 0 || it.kind > WPREP_F16 || !it.w || !it.dst || it.blocks <= 0) {
+                set_error("prepare_weights: bad item %d", i);
+                return SPRK_EINVAL;
+            }
+            t.it[t.n] = it;
+            t.start[t.n] = blocks;
+            blocks += it.blocks;
+            ++t.n;
+        }
+        if (t.n == 0) continue;
+        t.start[t.n] = blocks;
+        hipLaunchKernelGGL(wprep_kernel, dim3(blocks), dim3(256), 0, s, t);
+        if (int rc = check_launch("wprep")) return rc;
+    }
+    return SPRK_OK;
+}
+
+static thread_local sprk_wprep_item *t_wprep_describe = nullptr;
+static thread_local bool t_wprep_skip = false;
+WprepScope::WprepScope(sprk_wprep_item *describe, bool skip) {
+    t_wprep_describe = describe;
+    t_wprep_skip = skip;
+}
+WprepScope::~WprepScope() {
+    t_wprep_describe = nullptr;
+    t_wprep_skip = false;
+}
+bool wprep_describing() { return t_wprep_describe != nullptr; }
+int wprep_site(const sprk_wprep_item &it, hipStream_t s) {
+    if (t_wprep_describe) {
+        *t_wprep_describe = it;
+        return kWprepDescribed;
+    }
+    if (t_wprep_skip) return SPRK_OK;
+    return wprep_launch(&it, 1, s);
+}
+
 }  // namespace sprk
 
 extern "C" {
+
+int sprk_prepare_weights(const sprk_wprep_item *items, int n, void *stream) {
+    SPRK_REQUIRE(n >= 0 && (n == 0 || items), "prepare_weights: bad arguments");
+    return sprk::wprep_launch(items, n, (hipStream_t)stream);
+}
 
 int sprk_reduce_items(const sprk_reduce_item *items, int n, void *stream) {
     SPRK_REQUIRE(n >= 0 && (n == 0 || items), "reduce_items: bad arguments");
@@ -161,6 +235,7 @@ size_t sprk_struct_bytes(int which) {
     case 1: return sizeof(sprk_conv_epilogue);
     case 2: return sizeof(sprk_reduce_item);
     case 3: return sizeof(sprk_adam_item);
+    case 4: return sizeof(sprk_wprep_item);
     default: return 0;
     }
 }

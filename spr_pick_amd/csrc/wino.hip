@@ -21,6 +21,7 @@
 
 #include "common.h"
 #include "wino.h"
+#include "wprep_dev.h"
 
 namespace {
 
@@ -59,7 +60,7 @@ __device__ __forceinline__ float act_fn(float v, int act) {
     return v;
 }
 
-constexpr int CK = 4;                                  // channels per chunk = one MFMA k-step per position
+constexpr int CK = sprk::kWinoCK;                      // channels per chunk = one MFMA k-step per position
 // Workgroup geometry: 64 tiles as 4 x 16 (8 x 32 output pixels; images whose width is a multiple of 32) or as
 // 8 x 8 (16 x 16 output pixels; widths that are only a multiple of 16, e.g. the 16 x 16 U-Net level)
 template <int SQ>
@@ -84,53 +85,9 @@ __host__ __device__ constexpr size_t lds_bytes_of(int NT) {
                                                                                 // exchange + epilogue constants
 }
 
-// U[group][chunk][pos][nt][k][16] = (G g G^T)[pos] of the tap matrix of (output channel (group*NT + nt)*16 + j,
-// GEMM-k channel of chunk/k); zero rows for the channels a source's last chunk does not have, zero columns
-// past Cout.
-//   mode 0: g = w[cout][cin][u][v]           (forward)
-//   mode 1: g = w[k][n][2-u][2-v]            (backward-data: k = forward output channel, n = forward input)
-__global__ void wino_weights_kernel(const float *__restrict__ w, float *__restrict__ U, int Cout, int C1, int C2,
-                                    int nc1, int nch, int NT, int groups, int mode) {
-    const long total = (long)groups * nch * NT * CK * 16;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const int j = e % 16;
-    long r = e / 16;
-    const int k = r % CK;
-    r /= CK;
-    const int nt = r % NT;
-    r /= NT;
-    const int c = r % nch, grp = r / nch;
-    const int co = (grp * NT + nt) * 16 + j;
-    int ci = -1;
-    if (c < nc1) {
-        if (c * CK + k < C1) ci = c * CK + k;
-    } else if ((c - nc1) * CK + k < C2) {
-        ci = C1 + (c - nc1) * CK + k;
-    }
-    float g[3][3] = {};
-    if (ci >= 0 && co < Cout) {
-        const int Cin = C1 + C2;
-        for (int t = 0; t < 9; ++t) {
-            const int u = t / 3, v = t % 3;
-            g[u][v] = mode == 0 ? w[((long)co * Cin + ci) * 9 + t] : w[((long)ci * Cout + co) * 9 + (2 - u) * 3 + (2 - v)];
-        }
-    }
-    float t4[4][3];
-    for (int v = 0; v < 3; ++v) {
-        t4[0][v] = g[0][v];
-        t4[1][v] = 0.5f * (g[0][v] + g[1][v] + g[2][v]);
-        t4[2][v] = 0.5f * (g[0][v] - g[1][v] + g[2][v]);
-        t4[3][v] = g[2][v];
-    }
-    float *dst = U + ((long)grp * nch + c) * (16 * NT * CK * 16) + (nt * CK + k) * 16 + j;
-    for (int i = 0; i < 4; ++i) {
-        const float u4[4] = {t4[i][0], 0.5f * (t4[i][0] + t4[i][1] + t4[i][2]), 0.5f * (t4[i][0] - t4[i][1] + t4[i][2]),
-                             t4[i][2]};
-        for (int q = 0; q < 4; ++q) dst[(long)(i * 4 + q) * NT * CK * 16] = u4[q];
-    }
-}
-
+// The pre-transformed weights U[group][chunk][pos][nt][k][16] = (G g G^T)[pos] are a prepared-weight item
+// (wprep_dev.h: wprep_wino): zero rows for the channels a source's last chunk does not have, zero columns past Cout;
+// mode 0: g = w[cout][cin][u][v] (forward), mode 1: g = w[k][n][2-u][2-v] (backward-data).
 template <int V>
 struct IC {
     static constexpr int value = V;
@@ -718,9 +675,8 @@ int wino_conv(const WinoArgs &w, hipStream_t s) {
         return SPRK_EINVAL;
     }
     const long total = (long)groups * a.nch * NT * CK * 16;
-    hipLaunchKernelGGL(wino_weights_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, w.w, w.U, w.Cout, w.C1, w.C2, a.nc1,
-                       a.nch, NT, groups, w.mode);
-    if (int rc = check_launch("wino_weights")) return rc;
+    if (int rc = wprep_site(wprep_item(WPREP_WINO, w.w, w.U, total, {w.Cout, w.C1, w.C2, a.nc1, a.nch, NT, groups, w.mode}), s))
+        return rc;
     // persistent workgroups, one per CU: each walks tiles blockIdx.x, + gridDim.x, ... and starts the next tile's
     // loads under its output transform (same-box A/B: +5..7 % on the 48-channel layers with their short K loops,
     // +1.5 % on the 96-channel ones).  SPRK_WINO_PERSIST=0: one workgroup per tile.

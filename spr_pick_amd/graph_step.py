@@ -18,6 +18,8 @@ The all-reduce and the Adam update stay outside the graphs (eager): Adam is ONE 
 (``MultiAdam`` / ``sprk_adam_multi``) with the step count and the learning rate in device scalars, so the ramp
 needs no re-capture and no host sync.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -255,6 +257,20 @@ def set_lr(optimizer, lr):
             group["lr"] = lr
 
 
+class _NoPrep:
+    """SPRK_WPREP=0: every convolution call transforms its own weights (A/B measurements)."""
+    launches = 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def begin_step(self, like):
+        pass
+
+
 _SIDE = {}
 
 
@@ -283,6 +299,7 @@ class GraphedTrainStep:
         self.alpha, self.tau, self.world, self.mode = alpha, tau, world, mode
         self.use_graph = graph
         self.grads = FlatGrads(denoiser.parameters())
+        self.prep = ops.WeightPrep() if os.environ.get("SPRK_WPREP", "1") != "0" else _NoPrep()
         self.inp = torch.zeros(batch, 1, patch, patch, dtype=torch.float32, device=self.dev)
         self.tgt = torch.full((batch, 1), -1.0, dtype=torch.float32, device=self.dev)
         self._tgt_ring = PinnedRing((batch, 1), torch.float32, self.dev)
@@ -304,6 +321,13 @@ class GraphedTrainStep:
 
     # ---- one pass, eager (also what gets captured) ---------------------------------------------------
     def _pass(self, flip_p):
+        with self.prep:
+            # the weights changed since the last pass (the optimiser ran): every recorded weight transform of this
+            # step's convolutions in one launch, the calls below then skip their own (ops.WeightPrep)
+            self.prep.begin_step(self.inp)
+            return self._pass_body(flip_p)
+
+    def _pass_body(self, flip_p):
         data = DetectionDataset.make_batch(self.inp, self.tgt, hm=self._empty, hm_small=self._empty)
         if self.mode == "joint":
             if self.draw_eps:

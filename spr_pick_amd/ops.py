@@ -81,6 +81,92 @@ def _ws(nbytes, like):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
 
 
+class WeightPrep:
+    """Prepared weights (include/sprk.h, SPRK_DT_WPREP): the per-call weight transforms of the convolutions hoisted
+    into one launch per optimiser step.
+
+    While the context is open, the first forward / backward-data call of a (weight tensor, geometry, epilogue shape)
+    runs normally in a workspace that is KEPT, and the transform it ran is recorded as an item; from then on
+    ``begin_step()`` re-runs all recorded transforms in one launch per 40 (the weights changed: call it once per step,
+    before the first convolution) and the calls pass SPRK_DT_WPREP, i.e. skip their own transform launch.
+    Same device code either way: results are bit-identical.  Used by graph_step.GraphedTrainStep (the launch is the
+    first node of the captured graphs)."""
+
+    def __init__(self):
+        self.entries = {}        # key -> (workspace tensor, the weight tensor it was made from)
+        self.items = []          # _lib.WprepItem of every entry with a transform
+        self._table = None
+        self.launches = 0
+
+    def __enter__(self):
+        global _WPREP
+        self._outer, _WPREP = _WPREP, self
+        return self
+
+    def __exit__(self, *exc):
+        global _WPREP
+        _WPREP = self._outer
+        return False
+
+    def begin_step(self, like):
+        if not self.items:
+            return
+        if self._table is None or len(self._table) != len(self.items):
+            self._table = (_lib.WprepItem * len(self.items))(*self.items)
+        check(_lib.lib().sprk_prepare_weights(self._table, len(self.items), _stream(like)), "sprk_prepare_weights")
+        self.launches += 1
+
+    def lookup(self, key):
+        e = self.entries.get(key)
+        return e[0] if e is not None else None
+
+    def record(self, key, w, ws, item):
+        self.entries[key] = (ws, w)
+        if item.kind:
+            self.items.append(item)
+
+
+_WPREP = None
+
+
+def _prep_fwd(w, g, ep_key, ep):
+    """-> (geometry to call with, workspace or None).  Inside a WeightPrep context: the kept workspace of this
+    (weights, geometry, epilogue shape), with SPRK_DT_WPREP set once its transform is part of begin_step()."""
+    if _WPREP is None:
+        return g, None
+    key = ("f", w.data_ptr(), tuple(geom_list(g)), ep_key)
+    ws = _WPREP.lookup(key)
+    if ws is not None:
+        gp = ConvGeom(*geom_list(g))
+        gp.dtype = g.dtype | _lib.DT_WPREP
+        return gp, ws
+    L = _lib.lib()
+    ws = _ws(L.sprk_conv2d_fwd_ws_bytes(ctypes.byref(g)), w)
+    item = _lib.WprepItem()
+    check(L.sprk_conv2d_fwd_wprep(_p(w), ctypes.byref(g), ctypes.byref(ep), _p(ws), ws.numel(), ctypes.byref(item)),
+          "sprk_conv2d_fwd_wprep")
+    _WPREP.record(key, w, ws, item)
+    return g, ws          # this first call still runs its own transform, into the kept workspace
+
+
+def _prep_bwd(w, g):
+    if _WPREP is None:
+        return g, None
+    key = ("b", w.data_ptr(), tuple(geom_list(g)))
+    ws = _WPREP.lookup(key)
+    if ws is not None:
+        gp = ConvGeom(*geom_list(g))
+        gp.dtype = g.dtype | _lib.DT_WPREP
+        return gp, ws
+    L = _lib.lib()
+    ws = _ws(L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(g)), w)
+    item = _lib.WprepItem()
+    check(L.sprk_conv2d_bwd_data_wprep(_p(w), ctypes.byref(g), _p(ws), ws.numel(), ctypes.byref(item)),
+          "sprk_conv2d_bwd_data_wprep")
+    _WPREP.record(key, w, ws, item)
+    return g, ws
+
+
 def conv_out_size(n, k, stride, dil, pad_lo, pad_hi):
     return (n + pad_lo + pad_hi - dil * (k - 1) - 1) // stride + 1
 
@@ -109,7 +195,11 @@ def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None,
     """Raw forward launch (no autograd).  Returns y [N,Cout,Hout,Wout] ([N,Cout,2Hout,2Wout] with
     ``up_out``: nearest x2 upsampling fused into the store)."""
     _need_gpu(x, x2, w, bias, scale, shift, res)
-    return _S.conv2d_fwd(x, x2, w, bias, scale, shift, res, geom_list(g), int(res_off), int(act), 1 if up_out else 0)
+    ws = None
+    if _WPREP is not None:
+        ep = torch_ops._epilogue(bias, scale, shift, res, int(res_off), int(act), up_out)
+        g, ws = _prep_fwd(w, g, (bool(up_out), res is not None), ep)
+    return _S.conv2d_fwd(x, x2, w, bias, scale, shift, res, geom_list(g), int(res_off), int(act), 1 if up_out else 0, ws)
 
 
 class _Conv2dFn(torch.autograd.Function):
@@ -183,7 +273,10 @@ class _Conv2dFn(torch.autograd.Function):
             # x_act: x is the output of an activated layer that this convolution alone consumes — its activation
             # backward is fused into this backward-data call (the saved input is the mask)
             masked = ctx.x_act != ACT_NONE and gd.C2 == 0 and not gd.up1
-            gin = _S.conv2d_bwd_data(gsrc, wd, geom_list(gd), x if masked else None, ctx.x_act if masked else ACT_NONE)
+            ws_b = None
+            if wd is w:      # (a sliced weight is a new tensor every step: nothing to keep)
+                gd, ws_b = _prep_bwd(w, gd)
+            gin = _S.conv2d_bwd_data(gsrc, wd, geom_list(gd), x if masked else None, ctx.x_act if masked else ACT_NONE, ws_b)
             if ctx.x_act != ACT_NONE and not masked:
                 raise _lib.SprkError("conv2d: x_act needs a single, full-resolution input source")
             if gd.C2 == 0 and not gd.up1:

@@ -54,46 +54,53 @@ def geom_list(g):
 
 
 # ---- convolution -----------------------------------------------------------------------------------------------------
-def _conv2d_fwd(x, x2, w, bias, scale, shift, res, geom, res_off, act, up_out):
+def _epilogue(bias, scale, shift, res, res_off, act, up_out):
+    return ConvEpilogue(_p(bias), _p(scale), _p(shift), _p(res), 0 if res is None else res.shape[2],
+                        0 if res is None else res.shape[3], res_off, act, 1 if up_out else 0)
+
+
+def _conv2d_fwd(x, x2, w, bias, scale, shift, res, geom, res_off, act, up_out, ws):
+    """ws: a caller-owned workspace (prepared weights, ops.WeightPrep) or None = a fresh one."""
     L = _lib.lib()
     g = ConvGeom(*geom)
     m = 2 if up_out else 1
     y = _f32(x, (g.N, g.Cout, g.Hout * m, g.Wout * m))
-    ep = ConvEpilogue(_p(bias), _p(scale), _p(shift), _p(res), 0 if res is None else res.shape[2],
-                      0 if res is None else res.shape[3], res_off, act, 1 if up_out else 0)
-    nb = L.sprk_conv2d_fwd_ws_bytes(ctypes.byref(g))
-    ws = _ws(nb, x)
-    check(L.sprk_conv2d_fwd(_p(x), _p(x2), _p(w), _p(y), ctypes.byref(g), ctypes.byref(ep), _p(ws), nb, _stream(x)),
+    ep = _epilogue(bias, scale, shift, res, res_off, act, up_out)
+    if ws is None:
+        ws = _ws(L.sprk_conv2d_fwd_ws_bytes(ctypes.byref(g)), x)
+    check(L.sprk_conv2d_fwd(_p(x), _p(x2), _p(w), _p(y), ctypes.byref(g), ctypes.byref(ep), _p(ws), ws.numel(), _stream(x)),
           "sprk_conv2d_fwd")
     return y
 
 
-def _conv2d_fwd_fake(x, x2, w, bias, scale, shift, res, geom, res_off, act, up_out):
+def _conv2d_fwd_fake(x, x2, w, bias, scale, shift, res, geom, res_off, act, up_out, ws):
     m = 2 if up_out else 1
     return x.new_empty((geom[0], geom[6], geom[7] * m, geom[8] * m))
 
 
 _register("conv2d_fwd", "(Tensor x, Tensor? x2, Tensor w, Tensor? bias, Tensor? scale, Tensor? shift, Tensor? res, "
-                        "int[] geom, int res_off, int act, int up_out) -> Tensor", _conv2d_fwd, _conv2d_fwd_fake)
+                        "int[] geom, int res_off, int act, int up_out, Tensor? ws) -> Tensor", _conv2d_fwd, _conv2d_fwd_fake)
 
 
-def _conv2d_bwd_data(gy, w, geom, mask_y, mask_act):
+def _conv2d_bwd_data(gy, w, geom, mask_y, mask_act, ws):
     """mask_y / mask_act: fuse the activation backward of the layer that produced this convolution's input (the saved
-    input itself is the mask): the result is that layer's pre-activation gradient (sprk_conv2d_bwd_data_masked)."""
+    input itself is the mask): the result is that layer's pre-activation gradient (sprk_conv2d_bwd_data_masked).
+    ws: a caller-owned workspace (prepared weights) or None."""
     L = _lib.lib()
     g = ConvGeom(*geom)
     gin = _f32(gy, (g.N, g.C1 + g.C2, g.Hin, g.Win))
-    nb = L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(g))
-    ws = _ws(nb, gy)
+    if ws is None:
+        ws = _ws(L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(g)), gy)
     if mask_y is not None and tuple(mask_y.shape) != tuple(gin.shape):
         raise _lib.SprkError("conv2d_bwd_data: mask %s does not match the input gradient %s" % (tuple(mask_y.shape), tuple(gin.shape)))
     check(L.sprk_conv2d_bwd_data_masked(_p(gy), _p(w), _p(gin), ctypes.byref(g), _p(mask_y), int(mask_act) if mask_y is not None else 0,
-                                        _p(ws), nb, _stream(gy)), "sprk_conv2d_bwd_data_masked")
+                                        _p(ws), ws.numel(), _stream(gy)), "sprk_conv2d_bwd_data_masked")
     return gin
 
 
-_register("conv2d_bwd_data", "(Tensor gy, Tensor w, int[] geom, Tensor? mask_y, int mask_act) -> Tensor", _conv2d_bwd_data,
-          lambda gy, w, geom, mask_y, mask_act: gy.new_empty((geom[0], geom[1] + geom[2], geom[3], geom[4])))
+_register("conv2d_bwd_data", "(Tensor gy, Tensor w, int[] geom, Tensor? mask_y, int mask_act, Tensor? ws) -> Tensor",
+          _conv2d_bwd_data,
+          lambda gy, w, geom, mask_y, mask_act, ws: gy.new_empty((geom[0], geom[1] + geom[2], geom[3], geom[4])))
 
 
 # Pending second-stage sums (sprk_reduce_items): with defer=True the backward-weight / bias-gradient operators run only

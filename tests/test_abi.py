@@ -75,10 +75,10 @@ def test_torch_library_registration_and_fake_shapes():
         x = torch.empty(4, 48, 64, 64, device="cuda")
         w = torch.empty(96, 48, 3, 3, device="cuda")
         g = ops.make_geom(x, None, w, False, 1, 1, (2, 0, 1, 1))
-        y = torch.ops.sprk.conv2d_fwd(x, None, w, None, None, None, None, torch_ops.geom_list(g), 0, 1, 1)
+        y = torch.ops.sprk.conv2d_fwd(x, None, w, None, None, None, None, torch_ops.geom_list(g), 0, 1, 1, None)
         assert tuple(y.shape) == (4, 96, 128, 128)          # fused 2x upsampling store
         assert tuple(torch.ops.sprk.conv2d_bwd_data(torch.empty(4, 96, 64, 64, device="cuda"), w,
-                                                    torch_ops.geom_list(g), None, 0).shape) == (4, 48, 64, 64)
+                                                    torch_ops.geom_list(g), None, 0, None).shape) == (4, 48, 64, 64)
         assert tuple(torch.ops.sprk.shift_maxpool2_fwd(x, 1).shape) == (4, 48, 32, 32)
         assert tuple(torch.ops.sprk.rot4_stack_fwd(torch.empty(2, 1, 8, 8, device="cuda")).shape) == (8, 1, 8, 8)
         assert tuple(torch.ops.sprk.unrot4_shift_concat_fwd(torch.empty(8, 96, 8, 8, device="cuda")).shape) == (2, 384, 8, 8)

@@ -109,6 +109,8 @@ def test_replayed_step_equals_golden_and_eager_bit_for_bit(oracle_state):
     _check_golden(gw, first, den, st)
     st.prepare(inp, tgt, eps, epf)
     assert set(st._graphs) == {"w", "h"} and st.fallback_reason is None
+    # prepared weights: every convolution's weight transform is part of ONE launch at the head of the graph
+    assert len(st.prep.items) >= 80 and st.kernels_per_step < 280, (len(st.prep.items), st.kernels_per_step)
     for g in (gw, gh, gw):
         inp, tgt, eps, epf = batch(g)
         p = float(g["flip_p"])

@@ -863,3 +863,56 @@ def test_conv_pool_with_fused_activation_backward(shape, shift):
         scale = float(want.abs().max()) + 1e-30
         err = (got - want).abs()
         assert float(err.max()) <= 1e-2 * scale and int((err > 1e-4 * scale).sum()) <= max(1, err.numel() // 200), n
+
+
+PREP_CASES = ["enc1.2 shift 48->48 @64", "dec1.0 shift up(96)+1->96 @64", "dec1.2 shift 96->96 @64", "enc4 shift 48->48 @8",
+              "head 1x1 384->384 @64", "head 1x1 96->2 @64", "det 3x3 d2 s2 32->64 @21", "det conv7 s2 1->32 @64"]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16!"])
+@pytest.mark.parametrize("name", PREP_CASES)
+def test_prepared_weights_are_bit_identical_to_per_call_transforms(name, dt):
+    """ops.WeightPrep / SPRK_DT_WPREP: after the weights change, ONE sprk_prepare_weights launch re-runs the recorded
+    transforms and the convolution calls skip their own — outputs and every gradient bit-identical to the plain calls
+    (direct implicit GEMM, Winograd and 16-bit kernels; forward and backward-data)."""
+    from spr_pick_amd import _lib, ops
+    case = next(c for c in CONV_CASES if c[0] == name)
+    _, N, C1, C2, H, W, up1, Cout, K, stride, dil, pad, act, has_bias = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    h1, w1 = (H // 2, W // 2) if up1 else (H, W)
+    d = dev()
+    x = torch.randn(N, C1, h1, w1, generator=g).to(d)
+    x2 = torch.randn(N, C2, H, W, generator=g).to(d) if C2 else None
+    w = (torch.randn(Cout, C1 + C2, K, K, generator=g) * 0.1).to(d)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(d) if has_bias else None
+    code = _lib.DTYPES[dt]
+
+    def run(wv):
+        xs = x.clone().requires_grad_(True)
+        ws_ = wv.clone().requires_grad_(True)       # (a fresh tensor: plain path)
+        y = ops.conv2d(xs, ws_, b, x2=x2, up1=bool(up1), stride=stride, dil=dil, pad=pad, act=act, dtype=code)
+        y.sum().backward()
+        return y.detach(), xs.grad
+
+    prep = ops.WeightPrep()
+    wp = w.clone().requires_grad_(True)             # the persistent parameter of the prepared path
+
+    def run_prep():
+        xs = x.clone().requires_grad_(True)
+        with prep:
+            prep.begin_step(x)
+            y = ops.conv2d(xs, wp, b, x2=x2, up1=bool(up1), stride=stride, dil=dil, pad=pad, act=act, dtype=code)
+            y.sum().backward()
+        return y.detach(), xs.grad
+
+    y0, gx0 = run(w)
+    y1, gx1 = run_prep()                            # records, transforms inside the calls
+    assert torch.equal(y0, y1) and torch.equal(gx0, gx1)
+    n_items = len(prep.items)
+    with torch.no_grad():
+        wp.mul_(1.25).add_(0.01)                    # "the optimiser ran"
+    y2, gx2 = run_prep()                            # one launch for all items, calls skip their transform
+    y3, gx3 = run(wp.detach())
+    assert prep.launches == (1 if n_items else 0) and len(prep.items) == n_items
+    assert torch.equal(y2, y3) and torch.equal(gx2, gx3), (float((y2 - y3).abs().max()), float((gx2 - gx3).abs().max()))
+    assert not torch.equal(y2, y1)
