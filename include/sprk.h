@@ -122,6 +122,19 @@ int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y,
 size_t sprk_conv2d_bwd_data_ws_bytes(const sprk_conv_geom *g);
 int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk_conv_geom *g,
                          void *ws, size_t ws_bytes, void *stream);
+/* ---- fused per-pixel head (inference) ------------------------------------------------------------------------------
+ * out = W3 . lrelu(W2 . lrelu(W1 . f + b1) + b2) + b3 in ONE launch, LeakyReLU(0.1): the output_block + output_conv of
+ * the blind-spot U-Net (K0 = N1 = 384, N3 = 2: models/joint_network_v2.py:123-153, 241-244) and of the sigma net
+ * (K0 = N1 = 96, N3 = 1: models/joint_network_v2_shallow.py).  The middle width is 96.  A 128-pixel tile stays in the
+ * workgroup from the input features to the outputs: the two hidden tensors (2 x 25.8 GB at 4096^2) never reach HBM.
+ * f [B,K0,HW], w1 [N1,K0], w2 [96,N1], w3 [N3,96] (the reference's [Cout,Cin,1,1] layouts), out [B,N3,HW]; HW % 128 == 0.
+ * Same channel order in every sum as three sprk_conv2d_fwd calls, another tiling: results agree to fp32 rounding.
+ * Training keeps the three calls (the hidden activations are needed by the weight gradients). */
+size_t sprk_head1x1_fwd_ws_bytes(int K0, int N1);
+int sprk_head1x1_fwd(const float *f, const float *w1, const float *b1, const float *w2, const float *b2,
+                     const float *w3, const float *b3, float *out, int B, int K0, int N1, int N3, long HW, void *ws,
+                     size_t ws_bytes, void *stream);
+
 /* The same with the activation backward of the layer that PRODUCED this convolution's input fused in:
  *   gin = (d loss / d conv input) * act'(mask_y),   mask_y = the saved conv input [N,C1+C2,Hin,Win] (post-activation
  * output of that layer), mask_act = its SPRK_ACT_*.  gin is then that layer's pre-activation gradient and its own

@@ -62,6 +62,8 @@ _SIGS = {
     "sprk_conv2d_fwd_wprep": (c_i, [c_f, ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue), c_vp, c_sz, ctypes.POINTER(WprepItem)]),
     "sprk_conv2d_bwd_data_wprep": (c_i, [c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, ctypes.POINTER(WprepItem)]),
     "sprk_prepare_weights": (c_i, [ctypes.POINTER(WprepItem), c_i, c_vp]),
+    "sprk_head1x1_fwd_ws_bytes": (c_sz, [c_i, c_i]),
+    "sprk_head1x1_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_long, c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_data_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_bwd_data": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_data_masked": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_f, c_i, c_vp, c_sz, c_vp]),

@@ -120,6 +120,7 @@ class ShiftMaxPool(nn.Module):
         return ops.shift_maxpool2(x, self.shift, x_act)
 
 
+FUSED_HEAD = True       # debug: False = the three 1x1 convolutions of a U-Net's head as separate launches in inference too
 FUSE_ACT_BWD = True     # debug: False = every convolution runs its own activation-backward pass
 
 
@@ -177,6 +178,13 @@ class _UNetBase(nn.Module):
         """pool(conv(x)): the LeakyReLU backward of `conv` runs inside the pooling backward."""
         fuse = torch.is_grad_enabled() and FUSE_ACT_BWD and conv.act != ACT_NONE
         return self._run_pool(block, conv(x, premasked=fuse), conv.act if fuse else ACT_NONE)
+
+    def _head(self, t):
+        """output_block (two 1x1 convolutions) + output_conv: in inference one fused launch (ops.head1x1)."""
+        c1, c2, c3 = self.output_block[0], self.output_block[2], self.output_conv
+        if FUSED_HEAD and ops.head1x1_eligible(t, c1, c2, c3):
+            return ops.head1x1(t, c1, c2, c3)
+        return c3(c2(c1(t)))
 
     @property
     def blindspot(self):
@@ -264,8 +272,7 @@ class DualNetwork(_UNetBase):
             t = self._chain(blk[0], blk[2], t, skip=skip, up_out=up_out)
         if self._blindspot:
             t = ops.unrot4_shift_concat(t)
-        t = self.output_block[2](self.output_block[0](t))
-        out = self.output_conv(t)
+        out = self._head(t)
         if self._blindspot and self.detect:
             return out, None
         return out
@@ -321,8 +328,7 @@ class DualNetworkShallow(_UNetBase):
         for blk, skip, up_out in ((self.decode_block_5, pool2, True), (self.decode_block_2, pool1, True),
                                   (self.decode_block_1, x, False)):
             t = self._chain(blk[0], blk[2], t, skip=skip, up_out=up_out)
-        t = self.output_block[2](self.output_block[0](t))
-        return self.output_conv(t)
+        return self._head(t)
 
     @staticmethod
     def input_wh_mul():

@@ -494,3 +494,21 @@ class _SsdnFn(torch.autograd.Function):
 def ssdn_nll_pme(x, out_stats, noise_std):
     """(loss [B,1] = per-image mean NLL, pme [B,1,H,W], model_std [1,B,H,W])."""
     return _SsdnFn.apply(x, out_stats, noise_std)
+
+
+def head1x1_eligible(f, c1, c2, c3):
+    """The fused inference head (sprk_head1x1_fwd) covers 384 -> 384 -> 96 -> {1, 2} and 96 -> 96 -> 96 -> {1, 2} with
+    LeakyReLU(0.1), fp32 operands, planes whose pixel count is a multiple of 128."""
+    K0, N1 = c1.weight.shape[1], c1.weight.shape[0]
+    return (not torch.is_grad_enabled() and f.is_cuda and f.dtype == torch.float32 and (K0, N1) in ((384, 384), (96, 96))
+            and tuple(c2.weight.shape[:2]) == (96, N1) and c3.weight.shape[1] == 96 and c3.weight.shape[0] in (1, 2)
+            and c1.kernel_size == (1, 1) and c1.act == ACT_LEAKY and c2.act == ACT_LEAKY and c3.act == ACT_NONE
+            and all(c.bias is not None and (c.mfma_dtype & 0xff) == 0 for c in (c1, c2, c3))
+            and (f.shape[2] * f.shape[3]) % 128 == 0 and f.shape[2] * f.shape[3] < (1 << 25) and f.shape[1] == K0)
+
+
+def head1x1(f, c1, c2, c3):
+    """out = c3(c2(c1(f))) for three 1x1 convolution modules, one launch (inference only, no autograd)."""
+    f = f.contiguous()
+    _need_gpu(f)
+    return _S.head1x1_fwd(f, c1.weight.contiguous(), c1.bias, c2.weight.contiguous(), c2.bias, c3.weight.contiguous(), c3.bias)

@@ -103,6 +103,25 @@ _register("conv2d_bwd_data", "(Tensor gy, Tensor w, int[] geom, Tensor? mask_y, 
           lambda gy, w, geom, mask_y, mask_act, ws: gy.new_empty((geom[0], geom[1] + geom[2], geom[3], geom[4])))
 
 
+def _head1x1_fwd(f, w1, b1, w2, b2, w3, b3):
+    """Fused per-pixel head (inference): [B,K0,H,W] -> [B,N3,H,W] (sprk_head1x1_fwd)."""
+    L = _lib.lib()
+    B, K0, H, W = f.shape
+    N1, N3 = w1.shape[0], w3.shape[0]
+    out = _f32(f, (B, N3, H, W))
+    nb = L.sprk_head1x1_fwd_ws_bytes(K0, N1)
+    if nb == 0:
+        raise _lib.SprkError("head1x1_fwd: no fused kernel for %d -> %d" % (K0, N1))
+    ws = _ws(nb, f)
+    check(L.sprk_head1x1_fwd(_p(f), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(out), B, K0, N1, N3, H * W, _p(ws), nb,
+                             _stream(f)), "sprk_head1x1_fwd")
+    return out
+
+
+_register("head1x1_fwd", "(Tensor f, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor w3, Tensor b3) -> Tensor", _head1x1_fwd,
+          lambda f, w1, b1, w2, b2, w3, b3: f.new_empty((f.shape[0], w3.shape[0], f.shape[2], f.shape[3])))
+
+
 # Pending second-stage sums (sprk_reduce_items): with defer=True the backward-weight / bias-gradient operators run only
 # their main kernel, and the ~80 small sums of a training step are finished together by ``reduce_pending``.  An entry
 # keeps its partial buffer alive until then; the destination must be kept alive by the caller (ops defers only

@@ -916,3 +916,37 @@ def test_prepared_weights_are_bit_identical_to_per_call_transforms(name, dt):
     assert prep.launches == (1 if n_items else 0) and len(prep.items) == n_items
     assert torch.equal(y2, y3) and torch.equal(gx2, gx3), (float((y2 - y3).abs().max()), float((gx2 - gx3).abs().max()))
     assert not torch.equal(y2, y1)
+
+
+@pytest.mark.parametrize("shape", [(2, 384, 64, 64, 2), (1, 384, 32, 96, 2), (3, 96, 16, 40, 1), (1, 96, 128, 128, 1),
+                                   (5, 384, 8, 16, 2)])
+def test_fused_head_matches_three_convolutions(shape):
+    """sprk_head1x1_fwd (one launch: 384 -> 384 -> 96 -> 2 or 96 -> 96 -> 96 -> 1 with LeakyReLU(0.1), the per-pixel head
+    of the U-Nets, joint_network_v2.py:123-153, 241-244) against the fp64 statement at the operator budget, and against
+    the three-launch HIP path."""
+    from spr_pick_amd import networks, ops
+    B, K0, H, W, N3 = shape
+    g = torch.Generator().manual_seed(K0 + H + N3)
+    f = torch.randn(B, K0, H, W, generator=g)
+    c1 = networks.Conv2d(K0, K0, 1, act=ops.ACT_LEAKY)
+    c2 = networks.Conv2d(K0, 96, 1, act=ops.ACT_LEAKY)
+    c3 = networks.Conv2d(96, N3, 1, act=ops.ACT_NONE)
+    with torch.no_grad():
+        for c in (c1, c2, c3):
+            c.weight.copy_(torch.randn(c.weight.shape, generator=g) * (1.5 / c.weight.shape[1] ** 0.5))
+            c.bias.copy_(torch.randn(c.bias.shape, generator=g) * 0.3)
+    fd = f.double()
+    h = F.leaky_relu(F.conv2d(fd, c1.weight.double(), c1.bias.double()), 0.1)
+    h = F.leaky_relu(F.conv2d(h, c2.weight.double(), c2.bias.double()), 0.1)
+    want = F.conv2d(h, c3.weight.double(), c3.bias.double())
+    d = dev()
+    for c in (c1, c2, c3):
+        c.to(d)
+    with torch.no_grad():
+        x = f.to(d)
+        assert ops.head1x1_eligible(x, c1, c2, c3)
+        got = ops.head1x1(x, c1, c2, c3)
+        three = c3(c2(c1(x)))
+    close(got, want, name="fused head")
+    close(got, three, name="fused vs three launches")
+    assert not ops.head1x1_eligible(x.requires_grad_(True), c1, c2, c3) or not torch.is_grad_enabled()
