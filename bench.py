@@ -484,6 +484,34 @@ def main():
                   "note": "same step, U-Net MFMA operands rounded to %s in forward, backward-data and backward-weight (fp32 "
                           "tensors, master weights, accumulation); layers the 16-bit kernels do not cover (1x1 backward-"
                           "weight, planes below 32x32, the detector, the output convolutions) run fp32" % args.also_dtype}
+        # roofline of this leg: its dominant kernels are HBM-bound (fp32 tensors in and out, 16x the matrix rate), so
+        # they are priced in algorithmic GB/s: three eager steps, the two 16-bit kernel classes bracketed by events
+        for kc in (5, 6):
+            prof_collect(L, kc)
+        L.sprk_prof_enable((1 << 5) | (1 << 6))
+        for i in range(3):
+            inp, tgt = batches[i % nb]
+            st2(inp, tgt, eager=True)
+            st2.grads.all_reduce(world)
+            opt.step()
+        fence()
+        L.sprk_prof_enable(0)
+        r16 = {}
+        for kc, nm16 in ((5, "conv16_tile_kernel / conv16_mfma_kernel / conv16_head_kernel (forward, backward-data)"),
+                         (6, "wgrad16_kernel / wgrad16_1x1_kernel (backward-weight)")):
+            n_, ms_, fl_, by_ = (ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double())
+            L.sprk_prof_collect_bytes(kc, ctypes.byref(n_), ctypes.byref(ms_), ctypes.byref(fl_), ctypes.byref(by_))
+            if ms_.value > 0:
+                r16[kc] = {"kernel": nm16, "launches": n_.value, "avg_launch_ms": ms_.value / max(n_.value, 1),
+                           "achieved": by_.value / (ms_.value * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": by_.value / (ms_.value * 1e-3) / 1e9 / PEAK_HBM_GBS, "bound": "hbm", "traffic": None,
+                           "achieved_tflops": fl_.value / (ms_.value * 1e-3) / 1e12, "ms_per_step": ms_.value / 3}
+        if r16:
+            dom16 = max(r16, key=lambda k: r16[k]["ms_per_step"])
+            second["roofline"] = dict(r16[dom16], note="algorithmic bytes = every input and output tensor once, fp32 "
+                                      "(SURVEY 8d formula per launch) / event time of the launches; 6.3 TB/s is what a "
+                                      "copy reaches on this part")
+            second["other_16bit_kernels"] = [v for k, v in r16.items() if k != dom16]
         value_of[args.also_dtype] = second["value"]
         del o2, st2
         den.set_conv_dtype(args.dtype)

@@ -135,6 +135,14 @@ int sprk_head1x1_fwd(const float *f, const float *w1, const float *b1, const flo
                      const float *w3, const float *b3, float *out, int B, int K0, int N1, int N3, long HW, void *ws,
                      size_t ws_bytes, void *stream);
 
+/* The blind-spot head reading the rotated stack itself: d [4B,C=96,P,P] (the output of decode_block_1) -> out [B,N3,P,P].
+ * Shift2d((1,0)) + chunk(4) + rotate({0,270,180,90}) + cat(dim=1) (joint_network_v2.py:230-239, i.e.
+ * sprk_unrot4_shift_concat_fwd) are the address computation of the kernel's input gather: the [B,384,P,P] feature tensor
+ * (25.8 GB at 4096^2) is neither written nor read.  Same arithmetic as unrot + sprk_head1x1_fwd: bit-identical. */
+int sprk_head1x1_unrot_fwd(const float *d, const float *w1, const float *b1, const float *w2, const float *b2,
+                           const float *w3, const float *b3, float *out, int B, int C, int P, int N3, void *ws,
+                           size_t ws_bytes, void *stream);
+
 /* The same with the activation backward of the layer that PRODUCED this convolution's input fused in:
  *   gin = (d loss / d conv input) * act'(mask_y),   mask_y = the saved conv input [N,C1+C2,Hin,Win] (post-activation
  * output of that layer), mask_act = its SPRK_ACT_*.  gin is then that layer's pre-activation gradient and its own
@@ -345,6 +353,10 @@ int sprk_nms2d(const float *scores, int H, int W, int r, float threshold,
  * FLOPs. */
 void sprk_prof_enable(int mask);
 int sprk_prof_collect(int kclass, long *launches, double *ms, double *flops);
+/* the same plus the summed ALGORITHMIC HBM bytes of the launches (every tensor read and written once, fp32): classes
+ * 5 (16-bit-operand forward / backward-data kernels) and 6 (16-bit-operand backward-weight kernels) are HBM-bound
+ * and are priced in GB/s; 0 for the other classes */
+int sprk_prof_collect_bytes(int kclass, long *launches, double *ms, double *flops, double *bytes);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,7 @@ _SIGS = {
     "sprk_prepare_weights": (c_i, [ctypes.POINTER(WprepItem), c_i, c_vp]),
     "sprk_head1x1_fwd_ws_bytes": (c_sz, [c_i, c_i]),
     "sprk_head1x1_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_long, c_vp, c_sz, c_vp]),
+    "sprk_head1x1_unrot_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_data_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
     "sprk_conv2d_bwd_data": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_data_masked": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_f, c_i, c_vp, c_sz, c_vp]),
@@ -99,6 +100,8 @@ _SIGS = {
     "sprk_gather_patches": (c_i, [c_vp, c_i, c_vp, c_vp, c_vp, c_f, c_i, c_i, c_i, c_vp]),
     "sprk_prof_enable": (None, [c_i]),
     "sprk_prof_collect": (c_i, [c_i, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "sprk_prof_collect_bytes": (c_i, [c_i, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                      ctypes.POINTER(ctypes.c_double)]),
 }
 
 EXPORTS = tuple(_SIGS)

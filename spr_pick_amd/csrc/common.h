@@ -17,6 +17,7 @@ extern std::atomic<long> g_launches, g_wino_launches;
 // event bracketing of the MFMA convolution launches (sprk_prof_*)
 void prof_begin(int kclass, double flops, hipStream_t s);
 void prof_end(int kclass, hipStream_t s);
+void prof_bytes(double bytes);   // algorithmic HBM bytes of the launch opened by prof_begin (HBM-bound kernel classes)
 
 inline int check_launch(const char *what) {
     g_launches.fetch_add(1, std::memory_order_relaxed);

@@ -886,6 +886,7 @@ static int run_tile(const Conv16Call &c, const PlanT &p, const float *x, const f
     static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
     k.diag = diag;
     prof_begin(c.kclass, c.flops, s);
+    prof_bytes(4.0 * c.N * ((double)(c.C1 + c.C2) * c.Hin * c.Win + (double)c.Cout * c.Hout * c.Wout * (c.up2 ? 4 : 1)));
     const int rc = dt == SPRK_DT_BF16 ? launch_tile<__bf16>(k, p, s) : launch_tile<_Float16>(k, p, s);
     if (rc) return rc;
     prof_end(c.kclass, s);
@@ -924,6 +925,7 @@ static int run_head(const Conv16Call &c, const float *x, const float *w, float *
         return (int)SPRK_OK;
     };
     prof_begin(c.kclass, c.flops, s);
+    prof_bytes(4.0 * c.N * ((double)(c.C1 + c.C2) * c.Hin * c.Win + (double)c.Cout * c.Hout * c.Wout * (c.up2 ? 4 : 1)));
     const int rc = dt == SPRK_DT_BF16 ? go(conv16_head_kernel<__bf16>) : go(conv16_head_kernel<_Float16>);
     if (rc) return rc;
     prof_end(c.kclass, s);
@@ -984,6 +986,7 @@ int conv16_run(const Conv16Call &c, const float *x, const float *x2, const float
     static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
     k.diag = diag;
     prof_begin(c.kclass, c.flops, s);
+    prof_bytes(4.0 * c.N * ((double)(c.C1 + c.C2) * c.Hin * c.Win + (double)c.Cout * c.Hout * c.Wout * (c.up2 ? 4 : 1)));
     const int rc = dt == SPRK_DT_BF16 ? launch16<__bf16>(k, p, s) : launch16<_Float16>(k, p, s);
     if (rc) return rc;
     prof_end(c.kclass, s);

@@ -24,7 +24,7 @@ void set_error(const char *fmt, ...) {
 struct ProfRec {
     hipEvent_t a, b;
     int kclass;
-    double flops;
+    double flops, bytes;
 };
 static std::mutex g_prof_mu;
 static int g_prof_mask = 0;   // bit k: kernel class k is bracketed by events
@@ -45,9 +45,16 @@ void prof_begin(int kclass, double flops, hipStream_t s) {
     }
     r.kclass = kclass;
     r.flops = flops;
+    r.bytes = 0.0;
     (void)hipEventRecord(r.a, s);
     g_recs.push_back(r);
     t_open = (int)g_recs.size() - 1;
+}
+
+void prof_bytes(double bytes) {
+    if (t_open < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (t_open < (int)g_recs.size()) g_recs[t_open].bytes = bytes;
 }
 
 void prof_end(int kclass, hipStream_t s) {
@@ -250,9 +257,13 @@ void sprk_prof_enable(int on) {
 }
 
 int sprk_prof_collect(int kclass, long *launches, double *ms, double *flops) {
+    return sprk_prof_collect_bytes(kclass, launches, ms, flops, nullptr);
+}
+
+int sprk_prof_collect_bytes(int kclass, long *launches, double *ms, double *flops, double *bytes) {
     std::lock_guard<std::mutex> lk(sprk::g_prof_mu);
     long n = 0;
-    double t = 0.0, f = 0.0;
+    double t = 0.0, f = 0.0, by = 0.0;
     std::vector<sprk::ProfRec> keep;
     for (auto &r : sprk::g_recs) {
         if (r.kclass != kclass) {
@@ -264,6 +275,7 @@ int sprk_prof_collect(int kclass, long *launches, double *ms, double *flops) {
             ++n;
             t += dt;
             f += r.flops;
+            by += r.bytes;
         }
         sprk::g_pool.push_back({r.a, r.b});
     }
@@ -271,6 +283,7 @@ int sprk_prof_collect(int kclass, long *launches, double *ms, double *flops) {
     if (launches) *launches = n;
     if (ms) *ms = t;
     if (flops) *flops = f;
+    if (bytes) *bytes = by;
     return SPRK_OK;
 }
 

@@ -47,6 +47,10 @@ __device__ __forceinline__ const float *uniform_ptr(const float *p) {
 __device__ __forceinline__ void bdma16(rsrc_t r, int voff, int soff, float *lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds_wave_base, 16, voff, soff, 0, 0);
 }
+__device__ __forceinline__ void bdma4(rsrc_t r, int voff, int soff, float *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void *)lds_wave_base, 4, voff, soff, 0, 0);
+}
+constexpr int kXZero = (int)0x80000000;   // beyond num_records: the DMA writes zeros
 __device__ __forceinline__ int lds_addr(const void *p) {
     return (int)(unsigned)(__SIZE_TYPE__)(const __attribute__((address_space(3))) char *)p;
 }
@@ -60,6 +64,7 @@ struct HeadArgs {
     float *out;                  // [B][N3][HW]
     int B, N3, tilesPerImage, ntiles;
     long HW;
+    int P;                       // ROT: side of the square plane, f = d
 };
 
 template <int K0, int N1>
@@ -78,7 +83,12 @@ struct HeadGeo {
     static constexpr size_t LDS_BYTES = (size_t)(REGA + NW2 * W2BUF + CONST) * 4;
 };
 
-template <int K0, int N1>
+// ROT (blind-spot U-Net): the input features are read straight out of the rotated stack d [4B][96][P][P] — the
+// Shift2d + chunk + rotate + concat of joint_network_v2.py:230-239 (sprk_unrot4_shift_concat_fwd) becomes the address
+// computation of the X gather: f[b, 96 k + c, i, j] = d[k B + b, c][u - 1][v], (u, v) = R_k(i, j), zero for u = 0.  Tiles
+// are then 8 rows x 16 columns (a row = one 16-pixel MFMA tile), so that every rotation reads 32- or 64-byte runs, and
+// the 25.8 GB tensor f (4096^2) is neither written nor read.
+template <int K0, int N1, bool ROT>
 __global__ __launch_bounds__(kHThreads, 1) void head_fwd_kernel(const HeadArgs a) {
     using G = HeadGeo<K0, N1>;
     constexpr int LDW1 = G::LDW1, MT = G::MT, STAGE = G::STAGE, ROUNDS = G::ROUNDS, NCH = K0 / kKC;
@@ -116,14 +126,48 @@ __global__ __launch_bounds__(kHThreads, 1) void head_fwd_kernel(const HeadArgs a
     const int boff = lds_addr(regA + kXFloats + lq * LDW1 + nq * 96 + l15);
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const int b = tile / a.tilesPerImage, p0 = (tile - b * a.tilesPerImage) * kTM;
+        const int b = tile / a.tilesPerImage, trem = tile - b * a.tilesPerImage;
+        const int p0 = trem * kTM;
         const float *fimg = a.f + (long)b * K0 * a.HW + p0;
+        // ROT: tile = 8 rows x 16 columns at (ty0, tx0); per thread the byte offsets of its 4 gather lanes (q: channel
+        // of the wave's pair, half of the 128 pixel positions) under the 4 rotations; outside the shifted plane: zeros
+        int ty0 = 0, tx0 = 0;
+        int xo[4][4];
+        if constexpr (ROT) {
+            const int tilesX = a.P >> 4;
+            const int tyi = trem / tilesX;
+            ty0 = tyi * 8;
+            tx0 = (trem - tyi * tilesX) * 16;
+            const int P = a.P;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = 2 * wave + (q >> 1), pos = (q & 1) * 64 + lane;
+                const int px = (pos + 16 * (ch & 1)) & 127;
+                const int i = ty0 + (px >> 4), j = tx0 + (px & 15);
+                const int cho = ch * (int)a.HW;
+                xo[0][q] = i >= 1 ? (cho + (i - 1) * P + j) * 4 : kXZero;
+                xo[1][q] = j <= P - 2 ? (cho + (P - 2 - j) * P + i) * 4 : kXZero;
+                xo[2][q] = i <= P - 2 ? (cho + (P - 2 - i) * P + (P - 1 - j)) * 4 : kXZero;
+                xo[3][q] = j >= 1 ? (cho + (j - 1) * P + (P - 1 - i)) * 4 : kXZero;
+            }
+        }
         auto issue = [&](int c, int st) {
-            // X: channels c*16 .. +15; one 16-byte DMA per thread
-            const rsrc_t xr = make_rsrc(uniform_ptr(fimg + (long)(c * kKC) * a.HW));
-            // per-channel offset: channel stride HW*4 bytes may exceed what voffset + soffset should carry for huge
-            // planes (HW * 16 channels * 4 < 2^31 for HW < 2^25 = 5792^2): checked on the host
-            bdma16(xr, xvoff + xch * (int)(a.HW * 4), 0, xdst_w + st * STAGE);
+            if constexpr (ROT) {
+                // chunk c = channels 16 cc .. of rotation group k; 4-byte gather lanes, 64 per instruction
+                const int k = __builtin_amdgcn_readfirstlane(c / 6), cc = c - 6 * k;
+                const rsrc_t xr = make_rsrc(uniform_ptr(a.f + (((long)k * a.B + b) * 96 + cc * kKC) * a.HW));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int off = k == 0 ? xo[0][q] : k == 1 ? xo[1][q] : k == 2 ? xo[2][q] : xo[3][q];
+                    bdma4(xr, off, 0, xdst_w + st * STAGE + q * 64);
+                }
+            } else {
+                // X: channels c*16 .. +15; one 16-byte DMA per thread
+                const rsrc_t xr = make_rsrc(uniform_ptr(fimg + (long)(c * kKC) * a.HW));
+                // per-channel offset: channel stride HW*4 bytes may exceed what voffset + soffset should carry for
+                // huge planes (HW * 16 channels * 4 < 2^31 for HW < 2^25 = 5792^2): checked on the host
+                bdma16(xr, xvoff + xch * (int)(a.HW * 4), 0, xdst_w + st * STAGE);
+            }
             const rsrc_t wr = make_rsrc(a.w1t + (long)c * W1F);
             float *wd = regA + st * STAGE + kXFloats;
 #pragma unroll
@@ -225,31 +269,49 @@ __global__ __launch_bounds__(kHThreads, 1) void head_fwd_kernel(const HeadArgs a
             }
         if (l15 == 0) {
             const float c0 = cst[N1 + 3 * kN2], c1 = cst[N1 + 3 * kN2 + 1];
-            float *o = a.out + (long)b * a.N3 * a.HW + p0 + wave * 16 + 4 * lq;
+            float *o = ROT ? a.out + (long)b * a.N3 * a.HW + (long)(ty0 + wave) * a.P + tx0 + 4 * lq
+                           : a.out + (long)b * a.N3 * a.HW + p0 + wave * 16 + 4 * lq;
             *reinterpret_cast<f32x4 *>(o) = (f32x4){s0[0] + c0, s0[1] + c0, s0[2] + c0, s0[3] + c0};
             if (a.N3 > 1) *reinterpret_cast<f32x4 *>(o + a.HW) = (f32x4){s1[0] + c1, s1[1] + c1, s1[2] + c1, s1[3] + c1};
         }
     }
 }
 
-template <int K0, int N1>
+template <int K0, int N1, bool ROT>
 int launch_head(const HeadArgs &a, hipStream_t s) {
     using G = HeadGeo<K0, N1>;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(head_fwd_kernel<K0, N1>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(head_fwd_kernel<K0, N1, ROT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess) {
             sprk::set_error("head1x1_fwd: cannot reserve %zu bytes of LDS", G::LDS_BYTES);
             return SPRK_ELAUNCH;
         }
         attr = true;
     }
-    hipLaunchKernelGGL((head_fwd_kernel<K0, N1>), dim3(std::min(a.ntiles, 256)), dim3(kHThreads), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((head_fwd_kernel<K0, N1, ROT>), dim3(std::min(a.ntiles, 256)), dim3(kHThreads), G::LDS_BYTES, s, a);
     return sprk::check_launch("head_fwd");
 }
 
 size_t w1_floats(int K0, int N1) { return (size_t)sprk::kWprepZeroFloats + (size_t)K0 * (N1 + 16); }
 size_t w2_floats(int N1) { return (size_t)sprk::kWprepZeroFloats + (size_t)N1 * kLDW2; }
+
+// P > 0: the input is the rotated stack d [4B][96][P][P] (ROT)
+int run_head(const float *f, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+             const float *b3, float *out, int B, int K0, int N1, int N3, long HW, int P, void *ws, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    float *wsf = (float *)ws;
+    float *w1t = wsf, *w2t = wsf + w1_floats(K0, N1);
+    // W^T slabs in the k-chunked layout of the implicit-GEMM kernels (rows = input channels, row stride = LDS stride)
+    const sprk_wprep_item items[2] = {
+        sprk::wprep_item(sprk::WPREP_DIRECT, w1, w1t, (long)w1_floats(K0, N1), {N1, K0, 1, 0, kKC, kKC, K0, N1, N1 + 16, 1}),
+        sprk::wprep_item(sprk::WPREP_DIRECT, w2, w2t, (long)w2_floats(N1), {kN2, N1, 1, 0, kKC, kKC, N1, kN2, kLDW2, 1})};
+    if (int rc = sprk::wprep_launch(items, 2, s)) return rc;
+    HeadArgs a{f, w1t + sprk::kWprepZeroFloats, w2t + sprk::kWprepZeroFloats, b1, b2, w3, b3, out, B, N3,
+               (int)(HW / kTM), (int)(B * (HW / kTM)), HW, P};
+    if (P > 0) return launch_head<384, 384, true>(a, s);
+    return K0 == 384 ? launch_head<384, 384, false>(a, s) : launch_head<96, 96, false>(a, s);
+}
 
 }  // namespace
 
@@ -273,17 +335,23 @@ int sprk_head1x1_fwd(const float *f, const float *w1, const float *b1, const flo
         sprk::set_error("head1x1_fwd: workspace %zu < %zu", ws_bytes, need);
         return SPRK_EWORKSPACE;
     }
-    hipStream_t s = (hipStream_t)stream;
-    float *wsf = (float *)ws;
-    float *w1t = wsf, *w2t = wsf + w1_floats(K0, N1);
-    // W^T slabs in the k-chunked layout of the implicit-GEMM kernels (rows = input channels, row stride = LDS stride)
-    const sprk_wprep_item items[2] = {
-        sprk::wprep_item(sprk::WPREP_DIRECT, w1, w1t, (long)w1_floats(K0, N1), {N1, K0, 1, 0, kKC, kKC, K0, N1, N1 + 16, 1}),
-        sprk::wprep_item(sprk::WPREP_DIRECT, w2, w2t, (long)w2_floats(N1), {kN2, N1, 1, 0, kKC, kKC, N1, kN2, kLDW2, 1})};
-    if (int rc = sprk::wprep_launch(items, 2, s)) return rc;
-    HeadArgs a{f, w1t + sprk::kWprepZeroFloats, w2t + sprk::kWprepZeroFloats, b1, b2, w3, b3, out, B, N3,
-               (int)(HW / kTM), (int)(B * (HW / kTM)), HW};
-    return K0 == 384 ? launch_head<384, 384>(a, s) : launch_head<96, 96>(a, s);
+    return run_head(f, w1, b1, w2, b2, w3, b3, out, B, K0, N1, N3, HW, 0, ws, stream);
+}
+
+int sprk_head1x1_unrot_fwd(const float *d, const float *w1, const float *b1, const float *w2, const float *b2,
+                           const float *w3, const float *b3, float *out, int B, int C, int P, int N3, void *ws,
+                           size_t ws_bytes, void *stream) {
+    SPRK_REQUIRE(d && w1 && b1 && w2 && b2 && w3 && b3 && out, "head1x1_unrot_fwd: null tensor");
+    SPRK_REQUIRE(C == 96, "head1x1_unrot_fwd: the blind-spot head has 4 x 96 input channels");
+    SPRK_REQUIRE(B > 0 && (N3 == 1 || N3 == 2) && P > 0 && P % 16 == 0 && (long)P * P < (1L << 25),
+                 "head1x1_unrot_fwd: needs P %% 16 == 0, P^2 < 2^25, 1 or 2 outputs");
+    SPRK_REQUIRE(((((uintptr_t)d | (uintptr_t)out | (uintptr_t)ws) & 15) == 0), "head1x1_unrot_fwd: tensors must be 16-byte aligned");
+    const size_t need = sprk_head1x1_fwd_ws_bytes(384, 384);
+    if (!ws || ws_bytes < need) {
+        sprk::set_error("head1x1_unrot_fwd: workspace %zu < %zu", ws_bytes, need);
+        return SPRK_EWORKSPACE;
+    }
+    return run_head(d, w1, b1, w2, b2, w3, b3, out, B, 384, 384, N3, (long)P * P, P, ws, stream);
 }
 
 }  // extern "C"

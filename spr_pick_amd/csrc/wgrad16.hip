@@ -581,6 +581,7 @@ static int wgrad16_run_1x1(const Wgrad16Call &c, const Plan1 &p, const float *x,
         return p.wide ? go(wgrad16_1x1_kernel<T, 4, 3, 6>) : go(wgrad16_1x1_kernel<T, 2, 3, 6>);
     };
     prof_begin(c.kclass, c.flops, s);
+    prof_bytes(4.0 * c.N * ((double)(c.C1 + c.C2) * c.H * c.W + (double)c.Cout * c.Hout * c.Wout));
     const int rc = (c.dtype & SPRK_DT_MASK) == SPRK_DT_BF16 ? pick(__bf16{}) : pick(_Float16{});
     if (rc) return rc;
     prof_end(c.kclass, s);
@@ -630,6 +631,7 @@ int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const flo
         return p.MC == 6 ? go(wgrad16_kernel<T, 6, 4>) : go(wgrad16_kernel<T, 3, 4>);
     };
     prof_begin(c.kclass, c.flops, s);
+    prof_bytes(4.0 * c.N * ((double)(c.C1 + c.C2) * c.H * c.W + (double)c.Cout * c.Hout * c.Wout));
     const int rc = dt == SPRK_DT_BF16 ? pick(__bf16{}) : pick(_Float16{});
     if (rc) return rc;
     prof_end(c.kclass, s);

@@ -120,6 +120,7 @@ class ShiftMaxPool(nn.Module):
         return ops.shift_maxpool2(x, self.shift, x_act)
 
 
+FUSED_UNROT = True      # debug: False = materialise the un-rotated [B,384,P,P] tensor in front of the fused head
 FUSED_HEAD = True       # debug: False = the three 1x1 convolutions of a U-Net's head as separate launches in inference too
 FUSE_ACT_BWD = True     # debug: False = every convolution runs its own activation-backward pass
 
@@ -167,10 +168,17 @@ class _UNetBase(nn.Module):
     # Activation backward fused into the neighbours (ops.conv2d: premasked / x_act).  Every conv -> conv and conv -> pool
     # link of the U-Nets qualifies (the intermediate tensor has exactly one consumer); the convolution side is taken
     # where the consumer's backward-data kernel applies the mask in its epilogue.
+    @staticmethod
+    def _fuse_chain(first, second):
+        """second(first(x)): may the LeakyReLU backward of `first` run inside `second`'s backward-data kernel?"""
+        return (torch.is_grad_enabled() and FUSE_ACT_BWD and first.act != ACT_NONE and second.kernel_size[0] == 3
+                and second.mfma_dtype == 0)
+
     def _chain(self, first, second, x, skip=None, up_out=False):
-        """second(first(x, skip)): the LeakyReLU backward of `first` runs inside `second`'s backward-data kernel."""
-        fuse = torch.is_grad_enabled() and FUSE_ACT_BWD and first.act != ACT_NONE and second.kernel_size[0] == 3 \
-            and second.mfma_dtype == 0
+        """second(first(x, skip)).  (Callers in the decoders write the two calls out, rebinding their variable, so that
+        the block's input is released before the second convolution allocates its output: three 25.8 GB tensors
+        instead of four at 4096^2.)"""
+        fuse = self._fuse_chain(first, second)
         t = first(x, skip=skip, premasked=fuse)
         return second(t, up_out=up_out, x_act=first.act if fuse else ACT_NONE)
 
@@ -269,8 +277,15 @@ class DualNetwork(_UNetBase):
         for blk, skip, up_out in ((self.decode_block_5, pool4, True), (self.decode_block_4, pool3, True),
                                   (self.decode_block_3, pool2, True), (self.decode_block_2, pool1, True),
                                   (self.decode_block_1, x, False)):
-            t = self._chain(blk[0], blk[2], t, skip=skip, up_out=up_out)
+            fuse_c = self._fuse_chain(blk[0], blk[2])
+            t = blk[0](t, skip=skip, premasked=fuse_c)
+            t = blk[2](t, up_out=up_out, x_act=blk[0].act if fuse_c else ACT_NONE)
         if self._blindspot:
+            c1, c2, c3 = self.output_block[0], self.output_block[2], self.output_conv
+            if FUSED_HEAD and FUSED_UNROT and ops.head1x1_unrot_eligible(t, c1, c2, c3):
+                # inference: Shift2d + un-rotation + concat are the input gather of the fused head
+                out = ops.head1x1_unrot(t, c1, c2, c3)
+                return (out, None) if self.detect else out
             t = ops.unrot4_shift_concat(t)
         out = self._head(t)
         if self._blindspot and self.detect:
@@ -327,7 +342,9 @@ class DualNetworkShallow(_UNetBase):
         t = e6[0](pool3, up_out=True)
         for blk, skip, up_out in ((self.decode_block_5, pool2, True), (self.decode_block_2, pool1, True),
                                   (self.decode_block_1, x, False)):
-            t = self._chain(blk[0], blk[2], t, skip=skip, up_out=up_out)
+            fuse_c = self._fuse_chain(blk[0], blk[2])
+            t = blk[0](t, skip=skip, premasked=fuse_c)
+            t = blk[2](t, up_out=up_out, x_act=blk[0].act if fuse_c else ACT_NONE)
         return self._head(t)
 
     @staticmethod

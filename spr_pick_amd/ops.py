@@ -512,3 +512,22 @@ def head1x1(f, c1, c2, c3):
     f = f.contiguous()
     _need_gpu(f)
     return _S.head1x1_fwd(f, c1.weight.contiguous(), c1.bias, c2.weight.contiguous(), c2.bias, c3.weight.contiguous(), c3.bias)
+
+
+def head1x1_unrot_eligible(d, c1, c2, c3):
+    """Blind-spot head straight from the rotated stack d [4B,96,P,P] (no [B,384,P,P] tensor): sprk_head1x1_unrot_fwd."""
+    if d.dim() != 4 or d.shape[0] % 4 or d.shape[1] != 96 or d.shape[2] != d.shape[3] or d.shape[2] % 16:
+        return False
+    K0, N1 = c1.weight.shape[1], c1.weight.shape[0]
+    return (not torch.is_grad_enabled() and d.is_cuda and d.dtype == torch.float32 and (K0, N1) == (384, 384)
+            and tuple(c2.weight.shape[:2]) == (96, 384) and c3.weight.shape[1] == 96 and c3.weight.shape[0] in (1, 2)
+            and c1.kernel_size == (1, 1) and c1.act == ACT_LEAKY and c2.act == ACT_LEAKY and c3.act == ACT_NONE
+            and all(c.bias is not None and (c.mfma_dtype & 0xff) == 0 for c in (c1, c2, c3))
+            and d.shape[2] * d.shape[3] < (1 << 25))
+
+
+def head1x1_unrot(d, c1, c2, c3):
+    d = d.contiguous()
+    _need_gpu(d)
+    return _S.head1x1_unrot_fwd(d, c1.weight.contiguous(), c1.bias, c2.weight.contiguous(), c2.bias, c3.weight.contiguous(),
+                                c3.bias)

@@ -122,6 +122,26 @@ _register("head1x1_fwd", "(Tensor f, Tensor w1, Tensor b1, Tensor w2, Tensor b2,
           lambda f, w1, b1, w2, b2, w3, b3: f.new_empty((f.shape[0], w3.shape[0], f.shape[2], f.shape[3])))
 
 
+def _head1x1_unrot_fwd(d, w1, b1, w2, b2, w3, b3):
+    """Blind-spot head on the rotated stack: d [4B,96,P,P] -> [B,N3,P,P] (sprk_head1x1_unrot_fwd)."""
+    L = _lib.lib()
+    B4, C, P, P2 = d.shape
+    if B4 % 4 or P != P2:
+        raise _lib.SprkError("head1x1_unrot_fwd: bad shape %s" % (tuple(d.shape),))
+    N3 = w3.shape[0]
+    out = _f32(d, (B4 // 4, N3, P, P))
+    nb = L.sprk_head1x1_fwd_ws_bytes(384, 384)
+    ws = _ws(nb, d)
+    check(L.sprk_head1x1_unrot_fwd(_p(d), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), _p(out), B4 // 4, C, P, N3, _p(ws), nb,
+                                   _stream(d)), "sprk_head1x1_unrot_fwd")
+    return out
+
+
+_register("head1x1_unrot_fwd", "(Tensor d, Tensor w1, Tensor b1, Tensor w2, Tensor b2, Tensor w3, Tensor b3) -> Tensor",
+          _head1x1_unrot_fwd,
+          lambda d, w1, b1, w2, b2, w3, b3: d.new_empty((d.shape[0] // 4, w3.shape[0], d.shape[2], d.shape[3])))
+
+
 # Pending second-stage sums (sprk_reduce_items): with defer=True the backward-weight / bias-gradient operators run only
 # their main kernel, and the ~80 small sums of a training step are finished together by ``reduce_pending``.  An entry
 # keeps its partial buffer alive until then; the destination must be kept alive by the caller (ops defers only

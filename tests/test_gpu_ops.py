@@ -950,3 +950,32 @@ def test_fused_head_matches_three_convolutions(shape):
     close(got, want, name="fused head")
     close(got, three, name="fused vs three launches")
     assert not ops.head1x1_eligible(x.requires_grad_(True), c1, c2, c3) or not torch.is_grad_enabled()
+
+
+@pytest.mark.parametrize("B,P,N3", [(2, 64, 2), (1, 32, 2), (1, 16, 1), (3, 96, 2)])
+def test_fused_head_on_the_rotated_stack_is_bit_identical_to_unrot_plus_head(B, P, N3):
+    """sprk_head1x1_unrot_fwd: Shift2d + chunk + rotate + concat (joint_network_v2.py:230-239) as the input gather of the
+    fused head — bit-identical to sprk_unrot4_shift_concat_fwd followed by sprk_head1x1_fwd (same values, same order),
+    which the previous test pins against fp64."""
+    from spr_pick_amd import networks, ops
+    g = torch.Generator().manual_seed(B * 100 + P)
+    dd = torch.randn(4 * B, 96, P, P, generator=g)
+    c1 = networks.Conv2d(384, 384, 1, act=ops.ACT_LEAKY)
+    c2 = networks.Conv2d(384, 96, 1, act=ops.ACT_LEAKY)
+    c3 = networks.Conv2d(96, N3, 1, act=ops.ACT_NONE)
+    with torch.no_grad():
+        for c in (c1, c2, c3):
+            c.weight.copy_(torch.randn(c.weight.shape, generator=g) * (1.5 / c.weight.shape[1] ** 0.5))
+            c.bias.copy_(torch.randn(c.bias.shape, generator=g) * 0.3)
+    d = dev()
+    for c in (c1, c2, c3):
+        c.to(d)
+    with torch.no_grad():
+        x = dd.to(d)
+        assert ops.head1x1_unrot_eligible(x, c1, c2, c3)
+        got = ops.head1x1_unrot(x, c1, c2, c3)
+        f = ops.unrot4_shift_concat(x)
+        if ops.head1x1_eligible(f, c1, c2, c3):
+            assert torch.equal(got, ops.head1x1(f, c1, c2, c3))
+        close(got, c3(c2(c1(f))), name="vs three launches")
+    assert tuple(got.shape) == (B, N3, P, P)
