@@ -12,7 +12,7 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py --cpu-seconds 12 > $OUT/bench.log 2>&1
 grep '^{"metric"' $OUT/bench.log > $OUT/bench.json
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --infer-size 0 --infer-large 0 --also-dtype none --graph off"
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --infer-size 0 --infer-large 0 --also-dtype none --graph off --sustain-seconds 0 --batch16 off"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python3 $R/bench.py $ARGS > $OUT/trace.log 2>&1
 grep '^{"metric"' $OUT/trace.log > $OUT/bench_under_rocprof.json
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -- python3 $R/bench.py $ARGS > $OUT/fetch.log 2>&1

@@ -19,6 +19,12 @@ void prof_begin(int kclass, double flops, hipStream_t s);
 void prof_end(int kclass, hipStream_t s);
 void prof_bytes(double bytes);   // algorithmic HBM bytes of the launch opened by prof_begin (HBM-bound kernel classes)
 
+// Per-DEVICE facts and one-time set-up (a process may drive any device; nothing here is per process):
+// compute units of the calling thread's current device (persistent kernels launch one workgroup per CU)
+int num_cus();
+// opt a kernel in to `bytes` of dynamic LDS on the current device (hipFuncSetAttribute once per device and function)
+int lds_optin(const void *kernel, size_t bytes, const char *what);
+
 inline int check_launch(const char *what) {
     g_launches.fetch_add(1, std::memory_order_relaxed);
     hipError_t e = hipGetLastError();

@@ -1217,7 +1217,8 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     // one workgroup per CU (the stages fill most of the LDS): never more workgroups than CUs, or the
     // surplus runs as a second, nearly empty round
     const int per = p->nChunks * p->nblkN;
-    static const int kWgBlocks = dbg_int("SPRK_WG_BLOCKS", 256);   // debug knob (sweeps); 256 = one per CU
+    static const int kWgKnob = dbg_int("SPRK_WG_BLOCKS", 0);   // debug knob (sweeps); default: one workgroup per CU
+    const int kWgBlocks = kWgKnob > 0 ? kWgKnob : sprk::num_cus();
     int groups = std::max(1, std::min(p->nTiles, kWgBlocks / per));
     p->tilesPerGroup = sprk::cdiv(p->nTiles, groups);
     p->groups = sprk::cdiv(p->nTiles, p->tilesPerGroup);
@@ -1485,6 +1486,8 @@ static int conv2d_bwd_data_impl(const float *gy, const float *w, float *gin, con
     if ((g->dtype & SPRK_DT_MASK) != SPRK_DT_F32 && !naive_of(g)) {
         const sprk::Conv16Call c16 = call16_bwd(g);
         if (sprk::conv16_eligible(c16)) {
+            // (a masked epilogue in conv16_tile_kernel<6> takes it from 231 to 256 VGPRs + 92 bytes of scratch — the next
+            // tile's fetch is in flight during the stores — and the bf16 step from 11.22 to 11.27 ms: in-place pass)
             if (int rc = sprk::conv16_run(c16, gy, nullptr, w, gin, ws, ws_bytes, s)) return rc;
             return mask_y ? mask_in_place(gin, mask_y, mask_act, g, s) : (int)SPRK_OK;
         }
@@ -1524,6 +1527,8 @@ static int conv2d_bwd_data_impl(const float *gy, const float *w, float *gin, con
     a.act = SPRK_ACT_NONE;
     fill_args(a, p);
     a.vec4 = (g->Win % 4 == 0) && (p.lgTC >= 2) && (((uintptr_t)gin & 15) == 0);
+    // (a masked epilogue in this kernel costs 26 VGPRs — 160 -> 186, two workgroups per CU instead of three — for
+    // every call, masked or not: measured in round 1 and again in round 3; the mask is applied by an in-place pass)
     const double flops = 2.0 * g->N * g->Hout * g->Wout * (double)g->Cout * Cin * g->KH * g->KW;
     const int kclass = (p.MT == 4 && p.NT == 6) ? 0 : 2;
     sprk::prof_begin(kclass, flops, s);

@@ -781,7 +781,7 @@ int launch_tile(const Tile16Args &k, const PlanT &p, hipStream_t s) {
     // persistent workgroups: one per CU (8 waves at 159-225 VGPRs fill it), shared among the output-channel blocks
     const int ntiles = p.imgGroups * p.tilesX * p.tilesY;
     static const int persist = getenv("SPRK_C16_PERSIST") ? atoi(getenv("SPRK_C16_PERSIST")) : 1;   // debug: 0 = one tile each
-    const int slots = std::max(1, 256 / p.nblkN);
+    const int slots = std::max(1, sprk::num_cus() / p.nblkN);
     dim3 grid(persist ? std::min(ntiles, slots) : ntiles, p.nblkN);
     auto go = [&](auto kernel) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -6,6 +6,7 @@
 #include "wgrad16.h"
 
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 namespace sprk {
@@ -18,6 +19,36 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(t_error, sizeof(t_error), fmt, ap);
     va_end(ap);
+}
+
+// ---- per-device facts -----------------------------------------------------------------------
+constexpr int kMaxDev = 64;
+int num_cus() {
+    static std::atomic<int> cus[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 256;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+int lds_optin(const void *kernel, size_t bytes, const char *what) {
+    static std::mutex mu;
+    static std::vector<std::tuple<int, const void *, size_t>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &d : done)
+        if (std::get<0>(d) == dev && std::get<1>(d) == kernel && std::get<2>(d) >= bytes) return SPRK_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        set_error("%s: cannot reserve %zu bytes of LDS", what, bytes);
+        return SPRK_ELAUNCH;
+    }
+    done.emplace_back(dev, kernel, bytes);
+    return SPRK_OK;
 }
 
 // ---- profiling: hipEvent pairs around the MFMA convolution launches ----------------------

@@ -280,16 +280,9 @@ __global__ __launch_bounds__(kHThreads, 1) void head_fwd_kernel(const HeadArgs a
 template <int K0, int N1, bool ROT>
 int launch_head(const HeadArgs &a, hipStream_t s) {
     using G = HeadGeo<K0, N1>;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(head_fwd_kernel<K0, N1, ROT>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES) != hipSuccess) {
-            sprk::set_error("head1x1_fwd: cannot reserve %zu bytes of LDS", G::LDS_BYTES);
-            return SPRK_ELAUNCH;
-        }
-        attr = true;
-    }
-    hipLaunchKernelGGL((head_fwd_kernel<K0, N1, ROT>), dim3(std::min(a.ntiles, 256)), dim3(kHThreads), G::LDS_BYTES, s, a);
+    if (int rc = sprk::lds_optin(reinterpret_cast<const void *>(head_fwd_kernel<K0, N1, ROT>), G::LDS_BYTES, "head1x1_fwd"))
+        return rc;
+    hipLaunchKernelGGL((head_fwd_kernel<K0, N1, ROT>), dim3(std::min(a.ntiles, sprk::num_cus())), dim3(kHThreads), G::LDS_BYTES, s, a);
     return sprk::check_launch("head_fwd");
 }
 

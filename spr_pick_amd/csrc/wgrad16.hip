@@ -496,7 +496,7 @@ static bool plan_wg16(const Wgrad16Call &c, PlanW *p) {
     const int CinTot = c.C1 + c.C2;
     p->tail = (CinTot > kCB && CinTot % kCB == 1) ? 1 : 0;
     p->nBlocks = cdiv(CinTot - p->tail, kCB);
-    const int wgs = std::max(1, 256 / p->nBlocks);         // workgroups per input-channel block: one per CU in all
+    const int wgs = std::max(1, num_cus() / p->nBlocks);   // workgroups per input-channel block: one per CU in all
     // vertical segments per strip: enough units to give every workgroup >= 2, segments of >= 4 regions
     int seg = 1;
     while ((long)c.N * p->regX * seg < 2L * wgs && p->regY % (seg * 2) == 0 && p->regY / (seg * 2) >= 4) seg *= 2;
@@ -530,7 +530,7 @@ static bool plan_wg1x1(const Wgrad16Call &c, Plan1 *p) {
     p->ciBlocks = cdiv(Cin, CI);
     const int blocks = p->coBlocks * p->ciBlocks;
     if (blocks > 64) return false;
-    const int parts = std::max(1, 256 / blocks);                                // one workgroup per CU in all
+    const int parts = std::max(1, num_cus() / blocks);                          // one workgroup per CU in all
     p->perPart = cdiv(regions, parts);
     p->parts = cdiv(regions, p->perPart);
     p->ldsBytes = 2 * (size_t)(CO + CI) * (64 * 2 + 16);

@@ -681,21 +681,10 @@ int wino_conv(const WinoArgs &w, hipStream_t s) {
     // loads under its output transform (same-box A/B: +5..7 % on the 48-channel layers with their short K loops,
     // +1.5 % on the 96-channel ones).  SPRK_WINO_PERSIST=0: one workgroup per tile.
     static const int persist = getenv("SPRK_WINO_PERSIST") ? atoi(getenv("SPRK_WINO_PERSIST")) : 1;
-    const dim3 grid(persist ? std::min(a.ntiles, std::max(1, 256 / groups)) : a.ntiles, groups);
+    const dim3 grid(persist ? std::min(a.ntiles, std::max(1, num_cus() / groups)) : a.ntiles, groups);
     const size_t lds = lds_bytes_of(NT);
-    // the four <NT, SQ> instantiations share one function-pointer type, hence one instance of this lambda: the
-    // "LDS opt-in done" flag is kept per instantiation explicitly
-    static bool attr_flags[2][2] = {{false, false}, {false, false}};
-    bool &attr_done = attr_flags[NT == 6 ? 1 : 0][sq ? 1 : 0];
     auto launch = [&](auto kernel) {
-        if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess) {
-                set_error("wino_conv: cannot reserve %zu bytes of LDS", lds);
-                return (int)SPRK_ELAUNCH;
-            }
-            attr_done = true;
-        }
+        if (int rc = lds_optin(reinterpret_cast<const void *>(kernel), lds, "wino_conv")) return rc;
         hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, s, a);
         return (int)SPRK_OK;
     };
@@ -737,7 +726,6 @@ int wino_wgrad(const WinoWgArgs &w, hipStream_t s) {
         return SPRK_EINVAL;
     }
     const int CinTot = w.C1 + w.C2;
-    static bool attr3 = false, attr1 = false;
     WgRanges rg{};
     int nr = 0;
     auto launch = [&](const float *src, int Csrc, int ci0) -> int {
@@ -745,15 +733,8 @@ int wino_wgrad(const WinoWgArgs &w, hipStream_t s) {
         wg_split(Csrc, &g48, &tail);
         WgKArgs a{src, w.gy, w.partial, w.N, Csrc, 0, ci0, CinTot, w.H, w.W, w.Cout, w.padT, w.padL, w.W / WRW, w.H / WRH, xcd_on()};
         if (g48 > 0) {
-            if (!attr3) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_wgrad_kernel<3>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLdsBytes) != hipSuccess) {
-                    set_error("wino_wgrad: cannot reserve %zu bytes of LDS", kWgLdsBytes);
-                    return SPRK_ELAUNCH;
-                }
-                attr3 = true;
-            }
-            const int parts = kWgParts / g48;   // K split: one workgroup per CU over all channel groups
+            if (int rc = lds_optin(reinterpret_cast<const void *>(wino_wgrad_kernel<3>), kWgLdsBytes, "wino_wgrad")) return rc;
+            const int parts = std::min(kWgParts, num_cus()) / g48;   // K split: one workgroup per CU over all channel groups
             prof_begin(w.kclass, w.flops * (48.0 * g48) / CinTot, s);
             hipLaunchKernelGGL(wino_wgrad_kernel<3>, dim3(parts, g48), dim3(kThreads), kWgLdsBytes, s, a);
             prof_end(w.kclass, s);
@@ -762,22 +743,15 @@ int wino_wgrad(const WinoWgArgs &w, hipStream_t s) {
             rg.parts[nr++] = parts;
         }
         if (tail > 0) {
-            if (!attr1) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(wino_wgrad_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgLdsBytes) != hipSuccess) {
-                    set_error("wino_wgrad: cannot reserve %zu bytes of LDS", kWgLdsBytes);
-                    return SPRK_ELAUNCH;
-                }
-                attr1 = true;
-            }
+            if (int rc = lds_optin(reinterpret_cast<const void *>(wino_wgrad_kernel<1>), kWgLdsBytes, "wino_wgrad")) return rc;
             WgKArgs t = a;
             t.cbase = 48 * g48;   // the tail group sits after the 48-channel groups
             prof_begin(w.kclass, w.flops * (double)tail / CinTot, s);
-            hipLaunchKernelGGL(wino_wgrad_kernel<1>, dim3(kWgParts, 1), dim3(kThreads), kWgLdsBytes, s, t);
+            hipLaunchKernelGGL(wino_wgrad_kernel<1>, dim3(std::min(kWgParts, num_cus()), 1), dim3(kThreads), kWgLdsBytes, s, t);
             prof_end(w.kclass, s);
             if (int rc = check_launch("wino_wgrad<1>")) return rc;
             rg.end[nr] = ci0 + Csrc;
-            rg.parts[nr++] = kWgParts;
+            rg.parts[nr++] = std::min(kWgParts, num_cus());
         }
         return SPRK_OK;
     };
