@@ -500,30 +500,40 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a
         constexpr int S = decltype(stage)::value, ks = decltype(kstp)::value;
         constexpr int trow = ks >> 1, tcol = 8 * (ks & 1);   // tiles 4 ks .. 4 ks + 3: tile row, first column
         const lds_cfp pa = lds_f(baseA[S]), pb = lds_f(baseB2[S]), pz = lds_f(baseB[S]);
+        // Both transforms in PACKED fp32 (v_pk_fma_f32 / v_pk_add_f32 on the register pairs ds_read2_b32 returns, with
+        // op_sel / neg modifiers doing the shuffles and signs): 30-36 VALU instructions per 36 MFMAs were a quarter of
+        // this loop's issue time; now 15-18.  Position 2 is carried NEGATED on both operands (x1 - x2 and z1 - z0), so the
+        // products are unchanged.
         float av[MT][4], bv[3][4];
+        const f32x2 sgn2 = {sgn, sgn}, zs2 = {zs, zs};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int o = mt * WRP + 2 * trow * MT * WRP + tcol;
-            float xv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xv[j] = __builtin_fmaf(pb[o + j], sgn, pa[o + j]);
-            av[mt][0] = xv[0] - xv[2];
-            av[mt][1] = xv[1] + xv[2];
-            av[mt][2] = xv[2] - xv[1];
-            av[mt][3] = xv[1] - xv[3];
+            const f32x2 pa01 = {pa[o], pa[o + 1]}, pa23 = {pa[o + 2], pa[o + 3]};
+            const f32x2 pb01 = {pb[o], pb[o + 1]}, pb23 = {pb[o + 2], pb[o + 3]};
+            const f32x2 x01 = __builtin_elementwise_fma(pb01, sgn2, pa01), x23 = __builtin_elementwise_fma(pb23, sgn2, pa23);
+            f32x2 a01, a23;
+            // (x0 - x2, x1 + x2)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(a01) : "v"(x01), "v"(x23));
+            // (x1 - x2, x1 - x3): the first is -(x2 - x1)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(a23) : "v"(x01), "v"(x23));
+            av[mt][0] = a01[0];
+            av[mt][1] = a01[1];
+            av[mt][2] = a23[0];   // negated
+            av[mt][3] = a23[1];
         }
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt) {
             const int o = nt * 16 + 2 * trow * 48 + tcol;
-            float z0 = pz[o], z1 = pz[o + 1];
-            if (zmix) {
-                z0 = __builtin_fmaf(pz[o + 48], zs, z0);
-                z1 = __builtin_fmaf(pz[o + 48 + 1], zs, z1);
-            }
-            bv[nt][0] = z0;
-            bv[nt][1] = z0 + z1;
-            bv[nt][2] = z0 - z1;
-            bv[nt][3] = z1;   // true value -z1: folded into the final transform
+            f32x2 z = {pz[o], pz[o + 1]};
+            if (zmix) z = __builtin_elementwise_fma((f32x2){pz[o + 48], pz[o + 48 + 1]}, zs2, z);
+            f32x2 b12;
+            // (z0 + z1, z1 - z0): the second is -(z0 - z1)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(b12) : "v"(z), "v"(z));
+            bv[nt][0] = z[0];
+            bv[nt][1] = b12[0];
+            bv[nt][2] = b12[1];   // negated
+            bv[nt][3] = z[1];     // true value -z1: folded into the final transform
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p)
