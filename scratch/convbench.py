@@ -20,6 +20,11 @@ SHAPES = {
     "net dec3.0 96+48->96@16 N256": (256, 96, 48, 16, 16, 0, 96, 3, (2, 0, 1, 1)),
     "net dec3.2 96->96@16 N256": (256, 96, 0, 16, 16, 0, 96, 3, (2, 0, 1, 1)),
     "sig dec2.0 96+48->96@32 N64": (64, 96, 48, 32, 32, 0, 96, 3, (1, 1, 1, 1)),
+    "net dec2.0 96+48->96@32 N256": (256, 96, 48, 32, 32, 0, 96, 3, (2, 0, 1, 1)),
+    "net dec2.2 96->96@32 N256": (256, 96, 0, 32, 32, 0, 96, 3, (2, 0, 1, 1)),
+    "sig dec1.2 96->96@64 N32": (32, 96, 0, 64, 64, 0, 96, 3, (1, 1, 1, 1)),
+    "sig dec1.0 96+1->96@64 N32": (32, 96, 1, 64, 64, 0, 96, 3, (1, 1, 1, 1)),
+    "net dec1.2 96->96@64 N128": (128, 96, 0, 64, 64, 0, 96, 3, (2, 0, 1, 1)),
     "det32->32@29 valid": (32, 32, 0, 29, 29, 0, 32, 3, (0, 0, 0, 0)),
     "det64->64@9 valid": (32, 64, 0, 9, 9, 0, 64, 3, (0, 0, 0, 0)),
     "enc48->48@4": (256, 48, 0, 4, 4, 0, 48, 3, (2, 0, 1, 1)),

@@ -717,9 +717,16 @@ bool wino_wgrad_eligible(const WinoGeom &g) {
     int g48, tail;
     if (g.C1 < 1 || !wg_split(g.C1, &g48, &tail)) return false;
     if (g.C2 > 0 && !wg_split(g.C2, &g48, &tail)) return false;
-    // the partial results (256 x Cout x Cin x 9 floats written, then reduced) are a fixed cost: only layers with
-    // >= 32 regions per workgroup are worth it (64x64 patches from batch 128 up; 32x32 layers stay direct)
-    if ((long)g.N * (g.H / WRH) * (g.W / WRW) < 8192) return false;
+    // The partial results (256 x Cout x Cin x 9 floats written, then reduced) and the per-workgroup final transform are
+    // fixed costs.  Measured against the direct kernel (round 3, after the packed transforms; scratch/convbench.py):
+    // 4096 regions (144->96 / 96->96 at 256 x 32^2): 589 -> 472 us, 365 -> 269 us; 2048 regions (96->96 at 32 x 64^2):
+    // 191 -> 178 us; 1024 regions (16^2 planes at 256 images, 32^2 at 64): 114 -> 132, 178 -> 247, 164 -> 242 us: slower.
+    // A one-channel tail group (the raw image concatenated into decode_block_1) is a launch of its own that costs a
+    // third of a full group whatever the size: 96+1->96 at 32 x 64^2 196 -> 236 us, so layers with a tail need 8192.
+    static const long min_regions = getenv("SPRK_WINO_WGRAD_MIN") ? atol(getenv("SPRK_WINO_WGRAD_MIN")) : 0;   // sweeps
+    const bool has_tail = (g.C1 % 48) != 0 || (g.C2 % 48) != 0;
+    const long need = min_regions > 0 ? min_regions : (has_tail ? 8192 : 2048);
+    if ((long)g.N * (g.H / WRH) * (g.W / WRW) < need) return false;
     if ((long)48 * g.H * g.W * 4 >= 0x7FFFFFFFL || (long)g.Cout * g.H * g.W * 4 >= 0x7FFFFFFFL) return false;
     return true;
 }

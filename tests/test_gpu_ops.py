@@ -686,7 +686,9 @@ def test_deferred_reductions_match_immediate(dtype):
         h = ops.conv2d(x, params[0], params[1], pad=(2, 0, 1, 1), act=ops.ACT_LEAKY, dtype=dt)
         h = ops.conv2d(h, params[2], params[3], pad=(2, 0, 1, 1), act=ops.ACT_LEAKY, dtype=dt)
         h.square().mean().backward()
-        assert torch_ops.pending_count(d) == 4
+        # two weight + two bias sums; the 48 -> 96 layer's weight gradient takes the Winograd backward-weight kernel at this
+        # size (2048 regions, fp32), which finishes its own partial sums: 3 pending then
+        assert torch_ops.pending_count(d) == (3 if dtype == "f32" else 4)
     assert torch_ops.pending_count(d) == 0
 
 
