@@ -94,20 +94,22 @@ __global__ __launch_bounds__(kBlk) void nms_round_kernel(const NmsArgs a) {
     // each thread owns 4 pixels of the 32x32 tile: rows (tid>>5) + 8k, column tid&31
     const int px = tid & 31;
     int und = 0;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int span = 2 * r + 1, nbox = span * span;
+    const float inv_span = 1.0f / (float)span;
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
         const int py = (tid >> 5) + 8 * k;
         const int y = ty0 + py, x = tx0 + px;
-        if (y >= H || x >= W) continue;
-        const unsigned char cur = USE_LDS ? S[(py + r) * side + px + r] : a.st[(long)y * W + x];
-        if (cur != UNDECIDED) continue;
-        const float my = USE_LDS ? F[(py + r) * side + px + r] : a.sc[(long)y * W + x];
+        const bool inside = y < H && x < W;
+        const unsigned char cur = !inside ? (unsigned char)NONCAND : USE_LDS ? S[(py + r) * side + px + r] : a.st[(long)y * W + x];
+        const bool active = cur == UNDECIDED;
+        const float my = !active ? 0.f : USE_LDS ? F[(py + r) * side + px + r] : a.sc[(long)y * W + x];
         int verdict = 0;  // 0 none found, 1 blocked by an undecided, 2 covered by a pick
         // Quick probe: the 8 immediate neighbours (all inside the disk for r >= 2).  On a score map — smooth at the scale
         // of a pixel — every pixel that is not a local maximum has a higher neighbour right next to it, so this settles
-        // it in <= 8 probes instead of a row-major walk over up to (2r+1)^2 positions that reaches the uphill side last
-        // (which neighbour blocks a pixel is irrelevant: a verdict "blocked" only postpones, see the header).
-        if (USE_LDS && r >= 2) {
+        // it in <= 8 probes (which neighbour blocks a pixel is irrelevant: "blocked" only postpones, see the header).
+        if (USE_LDS && r >= 2 && active) {
 #pragma unroll
             for (int q = 0; q < 8 && !verdict; ++q) {
                 const int di = q < 3 ? -1 : q < 5 ? 0 : 1;
@@ -120,22 +122,63 @@ __global__ __launch_bounds__(kBlk) void nms_round_kernel(const NmsArgs a) {
                 if (f > my || (f == my && (di > 0 || (di == 0 && dj > 0)))) verdict = s == PICKED ? 2 : 1;
             }
         }
-        for (int di = -r; di <= r && !verdict && !(a.diag & 2); ++di) {
-            const int yy = y + di;
-            if (yy < 0 || yy >= H) continue;
-            const int dm = s_dmax[di < 0 ? -di : di];
-            for (int dj = -dm; dj <= dm; ++dj) {
-                const int xx = x + dj;
-                if (xx < 0 || xx >= W || (di == 0 && dj == 0)) continue;
-                const unsigned char s = USE_LDS ? S[(py + r + di) * side + px + r + dj] : a.st[(long)yy * W + xx];
-                if (s != UNDECIDED && s != PICKED) continue;
-                const float f = USE_LDS ? F[(py + r + di) * side + px + r + dj] : a.sc[(long)yy * W + xx];
-                if (f > my || (f == my && (di > 0 || (di == 0 && dj > 0)))) {
-                    verdict = s == PICKED ? 2 : 1;
-                    break;
+        if ((a.diag & 8) && !verdict) verdict = 1;   // timing experiment: quick probe only, survivors stay undecided
+        if (USE_LDS && r >= 2) {
+            // The survivors (local maxima of their 3x3: ~10 % of the pixels of a noisy map) have to look at the whole
+            // disk.  One lane walking 1009 positions while 63 wait was 3/4 of a round's time; instead the WAVE scans
+            // each survivor's disk together: the leader's pixel travels by lane read (wavefront shuffle), every lane
+            // checks one position of the bounding box per step, rows from the centre outwards, and the 64 findings are
+            // combined by ballot.  "Covered by a higher-priority pick" wins over "blocked by an undecided one" — both are
+            // statements the fixed point allows (header), the former is final.
+            unsigned long long todo = __ballot(active && verdict == 0 && !(a.diag & 2));
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int ltid = wave * 64 + leader;
+                const int lpy = (ltid >> 5) + 8 * k, lpx = ltid & 31;
+                const float lmy = __shfl(my, leader, 64);
+                const int ly = ty0 + lpy, lx = tx0 + lpx;
+                int v = 0;
+                for (int t0 = 0; t0 < nbox && !v; t0 += 64) {
+                    const int t = t0 + lane;
+                    int found = 0;
+                    if (t < nbox) {
+                        const int rowj = (int)(((float)t + 0.5f) * inv_span), col = t - rowj * span;
+                        const int di = (rowj & 1) ? -((rowj + 1) >> 1) : (rowj >> 1), dj = col - r;
+                        const int adj = dj < 0 ? -dj : dj;
+                        const int yy = ly + di, xx = lx + dj;
+                        if (adj <= s_dmax[di < 0 ? -di : di] && (di | dj) != 0 && yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                            const int o = (lpy + r + di) * side + lpx + r + dj;
+                            const unsigned char s = S[o];
+                            if (s == UNDECIDED || s == PICKED) {
+                                const float f = F[o];
+                                if (f > lmy || (f == lmy && (di > 0 || (di == 0 && dj > 0)))) found = s == PICKED ? 2 : 1;
+                            }
+                        }
+                    }
+                    v = __ballot(found == 2) ? 2 : __ballot(found == 1) ? 1 : 0;
+                }
+                if (lane == leader) verdict = v;
+            }
+        } else {
+            for (int di = -r; di <= r && !verdict && active && !(a.diag & 2); ++di) {
+                const int yy = y + di;
+                if (yy < 0 || yy >= H) continue;
+                const int dm = s_dmax[di < 0 ? -di : di];
+                for (int dj = -dm; dj <= dm; ++dj) {
+                    const int xx = x + dj;
+                    if (xx < 0 || xx >= W || (di == 0 && dj == 0)) continue;
+                    const unsigned char s = USE_LDS ? S[(py + r + di) * side + px + r + dj] : a.st[(long)yy * W + xx];
+                    if (s != UNDECIDED && s != PICKED) continue;
+                    const float f = USE_LDS ? F[(py + r + di) * side + px + r + dj] : a.sc[(long)yy * W + xx];
+                    if (f > my || (f == my && (di > 0 || (di == 0 && dj > 0)))) {
+                        verdict = s == PICKED ? 2 : 1;
+                        break;
+                    }
                 }
             }
         }
+        if (!active) continue;
         // x-overflow wrap of picks near the right border onto column 0 of the next row
         if (!verdict && x == 0 && y >= 1) {
             const long me = (long)y * W;
