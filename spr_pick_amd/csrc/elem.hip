@@ -35,6 +35,41 @@ __global__ void shift_maxpool2_fwd_kernel(const float *__restrict__ x, float *__
     }
 }
 
+// the same with four outputs per thread (W % 8 == 0, 16-byte aligned planes): two float4 pairs in, one float4 out, no
+// 64-bit index division.  (The scalar kernel ran at 0.9 TB/s on the 3.2 GB encoder planes of a 4096^2 micrograph.)
+__device__ __forceinline__ float max4_first(float a, float b, float c, float d) {
+    float m = a;
+    if (b > m || b != b) m = b;
+    if (c > m || c != c) m = c;
+    if (d > m || d != d) m = d;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void shift_maxpool2_fwd_v4_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                    int NC, int H, int W, int shift) {
+    const int Ho = H >> 1, Wo4 = W >> 3;
+    const int per = Ho * Wo4;
+    for (int nc = blockIdx.y; nc < NC; nc += gridDim.y) {
+        const float *p = x + (long)nc * H * W;
+        float *q = y + (long)nc * Ho * (W >> 1);
+        for (int t = blockIdx.x * 256 + threadIdx.x; t < per; t += gridDim.x * 256) {
+            const int i = t / Wo4, j4 = t - i * Wo4;
+            const int ra = 2 * i - shift, rb = ra + 1;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 a0 = ra >= 0 ? *reinterpret_cast<const float4 *>(p + (long)ra * W + 8 * j4) : z;
+            const float4 a1 = ra >= 0 ? *reinterpret_cast<const float4 *>(p + (long)ra * W + 8 * j4 + 4) : z;
+            const float4 b0 = rb >= 0 ? *reinterpret_cast<const float4 *>(p + (long)rb * W + 8 * j4) : z;
+            const float4 b1 = rb >= 0 ? *reinterpret_cast<const float4 *>(p + (long)rb * W + 8 * j4 + 4) : z;
+            float4 o;
+            o.x = max4_first(a0.x, a0.y, b0.x, b0.y);
+            o.y = max4_first(a0.z, a0.w, b0.z, b0.w);
+            o.z = max4_first(a1.x, a1.y, b1.x, b1.y);
+            o.w = max4_first(a1.z, a1.w, b1.z, b1.w);
+            *reinterpret_cast<float4 *>(q + (long)i * (W >> 1) + 4 * j4) = o;
+        }
+    }
+}
+
 // one thread per x element: it receives the window's gradient iff it is the FIRST maximum of
 // its window in row-major order (torch's max_pool2d backward rule).
 __global__ void shift_maxpool2_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x,
@@ -519,6 +554,12 @@ extern "C" {
 int sprk_shift_maxpool2_fwd(const float *x, float *y, int NC, int H, int W, int shift, void *stream) {
     SPRK_REQUIRE(x && y && NC > 0 && H >= 2 && W >= 2 && shift >= 0, "shift_maxpool2_fwd: bad arguments");
     const long total = (long)NC * (H / 2) * (W / 2);
+    if (W % 8 == 0 && H % 2 == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0)) {
+        const int per = (H / 2) * (W / 8);
+        dim3 grid(std::min(sprk::cdiv(per, 256), 64), std::min(NC, 32768));
+        hipLaunchKernelGGL(shift_maxpool2_fwd_v4_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, shift);
+        return sprk::check_launch("shift_maxpool2_fwd_v4");
+    }
     hipLaunchKernelGGL(shift_maxpool2_fwd_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y,
                        NC, H, W, shift);
     return sprk::check_launch("shift_maxpool2_fwd");

