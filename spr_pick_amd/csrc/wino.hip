@@ -87,7 +87,9 @@ constexpr int kECFloats = 2 * 96;                      // per-channel (scale, sh
 
 // U of one chunk: [pos][nt][k][16]: the 64 lanes of a B read (k = lane / 16, channel = lane % 16) hit 64
 // consecutive floats (no padding, no bank conflicts), and every (pos, nt) operand sits a multiple of 256 bytes
-// from the lane's base address, which is what ds_read2st64_b32 encodes as an immediate
+// from the lane's base address, which is what ds_read2st64_b32 encodes as an immediate.  Even NT: [pos][nt / 2][k][16][2]
+// — the lane's operands of two channel tiles in one 8-byte read, pairs 512 bytes apart (ds_read2st64_b64): half the LDS
+// instructions and waits per position (every instruction between the MFMAs costs the SIMD ~6.5 cycles)
 __host__ __device__ constexpr int ufloats_of(int NT) { return 16 * NT * CK * 16; }
 __host__ __device__ constexpr size_t lds_bytes_of(int NT) {
     return (size_t)(2 * RAWF + 2 * ufloats_of(NT) + kEFloats + kECFloats) * 4;   // two stages + the output-transform
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     rawB[0] = lds_addr(Rb + lq * RPLANE + (2 * trow0 + rb) * RP + (4 - a.padL) + 2 * tcol0);
     rawA[1] = rawA[0] + RAWF * 4;
     rawB[1] = rawB[0] + RAWF * 4;
-    int bbase = lds_addr(Ub + (4 * pg) * NT * 64 + lane);
+    int bbase = lds_addr(Ub + (4 * pg) * NT * 64 + (NT % 2 == 0 ? 2 * lane : lane));
     asm volatile("" : "+v"(rawA[0]), "+v"(rawA[1]), "+v"(rawB[0]), "+v"(rawB[1]), "+v"(bbase));
 
     // lane (l15, lq): tiles 32 th + 16 mt + l15 of channel lq -> its A operands for the wave's 4 positions
@@ -249,9 +251,19 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     };
     auto loadb = [&](float (&bv)[NT], auto stage, auto pos) {
         constexpr int S = decltype(stage)::value, p = decltype(pos)::value;
-        const lds_cfp bp = lds_f(bbase);
+        if constexpr (NT % 2 == 0) {   // pairs of channel tiles: 8-byte reads, 512 bytes apart (ds_read2st64_b64)
+            typedef const __attribute__((address_space(3))) f32x2 *lds_cf2p;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[S * UFLOATS + (p * NT + nt) * 64];
+            for (int q = 0; q < NT / 2; ++q) {
+                const f32x2 v = *(lds_cf2p)(__SIZE_TYPE__)(unsigned)(bbase + (S * UFLOATS + (p * (NT / 2) + q) * 128) * 4);
+                bv[2 * q] = v[0];
+                bv[2 * q + 1] = v[1];
+            }
+        } else {
+            const lds_cfp bp = lds_f(bbase);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[S * UFLOATS + (p * NT + nt) * 64];
+        }
     };
 
 #ifdef WINO_STAMP

@@ -49,7 +49,8 @@ __device__ __forceinline__ void wprep_direct(const float *__restrict__ w, float 
     }
 }
 
-// Winograd: U[group][chunk][pos][nt][k][16] = (G g G^T)[pos]   (see wino.hip); one thread per (group, chunk, nt, k, j)
+// Winograd: U[group][chunk][pos][nt][k][16] = (G g G^T)[pos]   (see wino.hip; even NT: [pos][nt / 2][k][16][2]); one
+// thread per (group, chunk, nt, k, j)
 // p: Cout, C1, C2, nc1, nch, NT, groups, mode
 __device__ __forceinline__ void wprep_wino(const float *__restrict__ w, float *__restrict__ U, const int *p, long first,
                                            long stride) {
@@ -86,7 +87,10 @@ __device__ __forceinline__ void wprep_wino(const float *__restrict__ w, float *_
             t4[2][v] = 0.5f * (g[0][v] - g[1][v] + g[2][v]);
             t4[3][v] = g[2][v];
         }
-        float *dst = U + ((long)grp * nch + c) * (16 * NT * CK * 16) + (nt * CK + k) * 16 + j;
+        // inside a position: [nt][k][16], or for an even NT [nt / 2][k][16][2] — a lane's two channel tiles side by side,
+        // so that one 8-byte LDS read (two of them per ds_read2st64_b64) fetches both B operands
+        const int in_pos = (NT & 1) ? (nt * CK + k) * 16 + j : (nt >> 1) * (2 * CK * 16) + (k * 16 + j) * 2 + (nt & 1);
+        float *dst = U + ((long)grp * nch + c) * (16 * NT * CK * 16) + in_pos;
         for (int i = 0; i < 4; ++i) {
             const float u4[4] = {t4[i][0], 0.5f * (t4[i][0] + t4[i][1] + t4[i][2]), 0.5f * (t4[i][0] - t4[i][1] + t4[i][2]),
                                  t4[i][2]};
