@@ -183,13 +183,17 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
         rawcur = uniform_ptr(a.x + (long)n * a.C1 * HW + org);
         rawsrc2 = a.C2 > 0 ? uniform_ptr(a.x2 + (long)n * a.C2 * HW + org) : nullptr;
     };
-    auto issue_raw = [&](int c, float *dst) {
+    // chunks with fewer than CK channels: the last one of a source whose channel count is not a multiple of CK
+    const int rag1 = (a.C1 % CK) ? a.nc1 - 1 : -1, rag2 = (a.C2 % CK) ? a.nch - 1 : -1;
+    auto issue_raw = [&](int c, float *dst, auto ragged) {
         if (c == a.nc1) rawcur = rawsrc2;
-        const bool s1 = c < a.nc1;
-        const int have = s1 ? a.C1 - c * CK : a.C2 - (c - a.nc1) * CK;   // < CK only in a source's ragged last chunk
         const rsrc_t rs = make_rsrc(rawcur);
         rawcur += (long)CK * HW;
-        if (tid < RAWQ) bdma16(rs, dch < have ? voff : kXZero, 0, dst + wave * 256);
+        int vo = voff;
+        if constexpr (decltype(ragged)::value != 0)
+            if (c == rag1 || c == rag2) vo = dch < (c == rag1 ? a.C1 % CK : a.C2 % CK) ? voff : kXZero;
+        // lanes past the tile's RAWQ groups (wave 6) carry kXZero: zeros into the stage's padding, no lane mask
+        if (wave < 7) bdma16(rs, vo, 0, dst + wave * 256);
     };
     const float *Ug = a.U + (long)grp * a.nch * UFLOATS;
     auto issue_u = [&](int c, float *dst) {
@@ -278,9 +282,9 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     set_tile(tile);
     auto first_loads = [&]() {
         raw_begin();
-        issue_raw(0, Rb);
+        issue_raw(0, Rb, IC<1>{});
         issue_u(0, Ub);
-        if (nch > 1) issue_raw(1, Rb + RAWF);
+        if (nch > 1) issue_raw(1, Rb + RAWF, IC<1>{});
     };
     first_loads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -289,11 +293,13 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
     transform(IC<0>{}, aop[0]);
     __syncthreads();
     // iteration c: aop[c&1] = operands of chunk c, U[c&1] holds chunk c, raw[(c+1)&1] the raw tile of chunk c+1
-    auto iter = [&](auto par, int c, auto first) {
+    // checked = 0: the steady-state copies (a full chunk c + 2 exists), no compares and branches around the DMA
+    auto iter = [&](auto par, int c, auto first, auto checked) {
         constexpr int P = decltype(par)::value;
+        constexpr bool CHK = decltype(checked)::value != 0;
         STAMP(0);
-        if (c + 1 < nch) issue_u(c + 1, Ub + (1 - P) * UFLOATS);
-        if (c + 2 < nch) issue_raw(c + 2, Rb + P * RAWF);
+        if (!CHK || c + 1 < nch) issue_u(c + 1, Ub + (1 - P) * UFLOATS);
+        if (!CHK || c + 2 < nch) issue_raw(c + 2, Rb + P * RAWF, checked);
         STAMP(1);
         // the first position's 12 MFMAs go out before the next chunk's input transform: its LDS reads and ~40 VALU
         // instructions then run while the matrix pipe works, instead of in front of an idle pipe (both waves of a SIMD
@@ -343,11 +349,17 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
 #endif
     };
     for (;;) {
-        iter(IC<0>{}, 0, IC<1>{});
-        if (1 < nch) iter(IC<1>{}, 1, IC<0>{});
-        for (int c = 2; c < nch; c += 2) {
-            iter(IC<0>{}, c, IC<0>{});
-            if (c + 1 < nch) iter(IC<1>{}, c + 1, IC<0>{});
+        iter(IC<0>{}, 0, IC<1>{}, IC<1>{});
+        if (1 < nch) iter(IC<1>{}, 1, IC<0>{}, IC<1>{});
+        int c = 2;
+        if (rag1 < 0)
+            for (; c + 4 < nch; c += 2) {   // both iterations of the pair fetch a full chunk (not the last one: rag2)
+                iter(IC<0>{}, c, IC<0>{}, IC<0>{});
+                iter(IC<1>{}, c + 1, IC<0>{}, IC<0>{});
+            }
+        for (; c < nch; c += 2) {
+            iter(IC<0>{}, c, IC<0>{}, IC<1>{});
+            if (c + 1 < nch) iter(IC<1>{}, c + 1, IC<0>{}, IC<1>{});
         }
         // The stages are free again: start the next tile's first loads now, under this tile's output transform.
         const int e_n = n, e_by = by, e_bx = bx;
