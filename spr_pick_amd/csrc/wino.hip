@@ -492,7 +492,7 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
 constexpr int WRH = 4, WRW = 16, WRP = 24;
 constexpr int WPB = 4 * 3 * 16 + 4;
 constexpr int WAF = 4 * 2048, WSTAGE = 2 * WAF;
-constexpr size_t kWgLdsBytes = (size_t)(2 * WSTAGE + 8 * kThreads) * 4;   // two stages + the DMA lane table
+constexpr size_t kWgLdsBytes = (size_t)(2 * WSTAGE) * 4;   // two stages
 
 struct WgKArgs {
     const float *x, *gy;
@@ -515,44 +515,78 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a
     const int c0 = a.cbase + grp * 16 * MT;   // first channel of this group inside the source
     const int have = a.Csrc - c0;             // valid channels of this group
 
-    // DMA lane table (fixed per workgroup), kept in LDS: registers are the scarce resource here.  Byte offsets
-    // are multiples of 16: the raw row (15 = pad lane / missing channel, never inside the image) rides in the low
-    // bits of the raw entry, the raw column group in the low bits of the dY entry.
-    int *geo = reinterpret_cast<int *>(smem + 2 * WSTAGE) + tid;
-#pragma unroll
-    for (int rd = 0; rd < 4; ++rd) {
-        const int q = tid + rd * kThreads;
-        const int sl = q / (PA / 4), rem = q % (PA / 4);
-        const int row = rem / (6 * MT), mt = (rem % (6 * MT)) / 6, c4 = rem % 6;
-        const bool va = q < NA4 && rem < 36 * MT && 16 * mt + sl < have;
-        geo[(2 * rd) * kThreads] = (int)(((16 * mt + sl) * HW + (long)row * W + 4 * c4) * 4) | (va ? row : 15);
-        const int sb = q / (WPB / 4), remb = q % (WPB / 4);
-        const int rowb = remb / 12, ntb = (remb % 12) / 4, c4b = remb % 4;
-        const int chb = (sb >> 4) * 48 + 16 * ntb + (sb & 15);
-        geo[(2 * rd + 1) * kThreads] =
-            ((q < NB4 && remb < 48 && chb < a.Cout) ? (int)((chb * HW + (long)rowb * W + 4 * c4b) * 4) : kXZero) | c4;
-    }
-    auto issue = [&](int region, float *st) {
-        // wave-uniform, but integer division runs on the vector ALU: pull the results back into SGPRs so that
-        // the buffer descriptors are scalar (otherwise every DMA sits in a waterfall loop)
-        const int r0 = __builtin_amdgcn_readfirstlane(region);
-        const int q0 = __builtin_amdgcn_readfirstlane(r0 / a.regionsX);
-        const int rx = r0 - q0 * a.regionsX;
-        const int n = __builtin_amdgcn_readfirstlane(q0 / a.regionsY);
-        const int ry = q0 - n * a.regionsY;
-        const int y0 = ry * WRH, x0 = rx * WRW;
-        const float *xa = a.x + ((long)n * a.Csrc + c0) * HW + (long)(y0 - a.padT) * W + (x0 - 4);
-        const float *gb = a.gy + (long)n * a.Cout * HW + (long)y0 * W + x0;
-        const rsrc_t ra = make_rsrc(uniform_ptr(xa)), rb = make_rsrc(uniform_ptr(gb));
+    // DMA lane table, fixed per workgroup, in REGISTERS (12 of the ~70 the packed transforms freed; it lived in LDS and was
+    // re-read, unpacked and range-checked for every region: 195 instructions per region and wave, a quarter of the
+    // region's matrix time — every instruction a wave issues beside its MFMAs costs the SIMD ~6.5 cycles).
+    // Per slot: byte offset of the lane's 16 bytes inside the region's raw tile / gradient tile (kXZero: pad lane or
+    // missing channel), and for the raw tile a 16-bit mask: bit 4 yt + xt says whether the lane's row and column group
+    // lie inside the image for a region of row type yt / column type xt (0 first, 1 inner, 2 last, 3 first and last).
+    int offA[4], offB[4], mskA[4];
+    {
+        const int RY = a.regionsY, RX = a.regionsX;
 #pragma unroll
         for (int rd = 0; rd < 4; ++rd) {
-            const int pa_ = geo[(2 * rd) * kThreads], pb_ = geo[(2 * rd + 1) * kThreads];
-            const unsigned gyy = (unsigned)(y0 - a.padT + ((pa_ & 15) == 15 ? 0x100000 : (pa_ & 15)));
-            const unsigned gxx = (unsigned)(x0 - 4 + 4 * (pb_ & 15));
-            const bool ok = gyy < (unsigned)H && gxx < (unsigned)W;
-            bdma16(ra, ok ? (pa_ & ~15) : kXZero, 0, st + rd * 2048 + wave * 256);
-            bdma16(rb, pb_ & ~15, 0, st + WAF + rd * 2048 + wave * 256);
+            const int q = tid + rd * kThreads;
+            const int sl = q / (PA / 4), rem = q % (PA / 4);
+            const int row = rem / (6 * MT), mt = (rem % (6 * MT)) / 6, c4 = rem % 6;
+            const bool va = q < NA4 && rem < 36 * MT && 16 * mt + sl < have;
+            offA[rd] = va ? (int)(((16 * mt + sl) * HW + (long)row * W + 4 * c4) * 4) : kXZero;
+            int m = 0;
+#pragma unroll
+            for (int yt = 0; yt < 4; ++yt) {
+                const int ry = yt == 0 ? 0 : yt == 1 ? 1 : yt == 2 ? RY - 1 : 0;
+                const bool rok = (unsigned)(ry * WRH - a.padT + row) < (unsigned)H;
+#pragma unroll
+                for (int xt = 0; xt < 4; ++xt) {
+                    const int rx = xt == 0 ? 0 : xt == 1 ? 1 : xt == 2 ? RX - 1 : 0;
+                    const bool cok = (unsigned)(rx * WRW - 4 + 4 * c4) < (unsigned)W;
+                    m |= (rok && cok) ? 1 << (4 * yt + xt) : 0;
+                }
+            }
+            mskA[rd] = va ? m : 0;
+            const int sb = q / (WPB / 4), remb = q % (WPB / 4);
+            const int rowb = remb / 12, ntb = (remb % 12) / 4, c4b = remb % 4;
+            const int chb = (sb >> 4) * 48 + 16 * ntb + (sb & 15);
+            offB[rd] = (q < NB4 && remb < 48 && chb < a.Cout) ? (int)((chb * HW + (long)rowb * W + 4 * c4b) * 4) : kXZero;
         }
+    }
+    // region cursor (scalar): the workgroup walks regions slot, slot + gridDim.x, ...; (rx, ry, n) advance by the
+    // decomposed stride with carries instead of two divisions per region
+    int cur_rx, cur_ry, cur_n, d_rx, d_ry, d_n;
+    {
+        const int r0 = xcd_slot(blockIdx.x, gridDim.x, a.xcd);
+        const int q0 = r0 / a.regionsX;
+        cur_rx = __builtin_amdgcn_readfirstlane(r0 - q0 * a.regionsX);
+        cur_n = __builtin_amdgcn_readfirstlane(q0 / a.regionsY);
+        cur_ry = __builtin_amdgcn_readfirstlane(q0 - (q0 / a.regionsY) * a.regionsY);
+        const int st = gridDim.x, t0 = st / a.regionsX;
+        d_rx = __builtin_amdgcn_readfirstlane(st - t0 * a.regionsX);
+        d_n = __builtin_amdgcn_readfirstlane(t0 / a.regionsY);
+        d_ry = __builtin_amdgcn_readfirstlane(t0 - (t0 / a.regionsY) * a.regionsY);
+    }
+    const float *xbase = a.x + (long)c0 * HW - (long)a.padT * W - 4;
+    const long strideA = (long)a.Csrc * HW, strideB = (long)a.Cout * HW;
+    // issues the region under the cursor, then advances the cursor
+    auto issue = [&](float *st) {
+        const int RY = a.regionsY, RX = a.regionsX;
+        const int yt = RY == 1 ? 3 : cur_ry == 0 ? 0 : cur_ry == RY - 1 ? 2 : 1;
+        const int xt = RX == 1 ? 3 : cur_rx == 0 ? 0 : cur_rx == RX - 1 ? 2 : 1;
+        const int bit = 4 * yt + xt;
+        const int inimg = cur_ry * (WRH * W) + cur_rx * WRW;
+        const rsrc_t ra = make_rsrc(xbase + cur_n * strideA + inimg), rb = make_rsrc(a.gy + cur_n * strideB + inimg);
+#pragma unroll
+        for (int rd = 0; rd < 4; ++rd) {
+            const int m = __builtin_amdgcn_sbfe(mskA[rd], bit, 1);   // -1: inside the image
+            bdma16(ra, (offA[rd] & m) | (kXZero & ~m), 0, st + rd * 2048 + wave * 256);
+            bdma16(rb, offB[rd], 0, st + WAF + rd * 2048 + wave * 256);
+        }
+        cur_rx += d_rx;
+        const int cx = cur_rx >= RX;
+        cur_rx -= cx ? RX : 0;
+        cur_ry += d_ry + cx;
+        const int cy = cur_ry >= RY;
+        cur_ry -= cy ? RY : 0;
+        cur_n += d_n + cy;
     };
 
     f32x4 acc[4][MT][3];
@@ -628,7 +662,7 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a
         constexpr int S = decltype(stage)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (region + (int)gridDim.x < nregions) issue(region + gridDim.x, smem + (1 - S) * WSTAGE);
+        if (region + (int)gridDim.x < nregions) issue(smem + (1 - S) * WSTAGE);
         // (no scheduling fences between the k-steps any more: with the packed transforms the kernel has 186 VGPRs and no
         // spills, and the compiler may run a k-step's LDS reads under the previous one's MFMAs: 446.5 -> 442 us)
         kstep(stage, IC<0>{});
@@ -638,7 +672,7 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a
     };
 
     int region = xcd_slot(blockIdx.x, gridDim.x, a.xcd);
-    if (region < nregions) issue(region, smem);
+    if (region < nregions) issue(smem);
     for (; region < nregions; region += 2 * gridDim.x) {
         stage_body(IC<0>{}, region);
         if (region + (int)gridDim.x < nregions) stage_body(IC<1>{}, region + gridDim.x);
@@ -833,7 +867,7 @@ bool wino_wgrad_eligible(const WinoGeom &g) {
     if (!on) return false;
     if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.dil != 1 || g.up1) return false;
     if (g.Hout != g.H || g.Wout != g.W || g.H % WRH || g.W % WRW) return false;
-    if (g.padL < 0 || g.padL > 4 || g.padT < 0) return false;
+    if (g.padL < 0 || g.padL > 4 || g.padT < 0 || g.padT > 4) return false;   // padT <= 4: inner regions see no border
     if (g.Cout < 81 || g.Cout > 96) return false;   // two halves of 3 channel tiles
     int g48, tail;
     if (g.C1 < 1 || !wg_split(g.C1, &g48, &tail)) return false;
