@@ -330,6 +330,7 @@ struct WgArgs {
     int xtab;                // buffer-load staging of the row tiles (G, and x for 1x1)
     int nG1, nG2;            // MODE 2: 256-float groups per staged x plane (source 1 / 2): table staging
     float invImg, invPitch;
+    int diag;                // timing experiments only (SPRK_WG_DIAG): 1 = stage the first tile of a group only
 };
 
 // one 64-pixel tile: 16 k-steps of MFMAs on NIT k-tiles x NT cout-tiles, software pipelined by hand: the LDS
@@ -538,6 +539,7 @@ __global__ __launch_bounds__(256 * WJ) void conv_wgrad_mfma_kernel(const WgArgs 
         }
     };
     auto issue = [&](int tile, int b) {
+        if (a.diag && tile != (int)blockIdx.x * a.tilesPerGroup) return;
         int t = tile;
         const int tx = t % a.tilesX;
         t /= a.tilesX;
@@ -1631,6 +1633,8 @@ int sprk_conv2d_bwd_weight_partial(const float *x, const float *x2, const float 
     // MODE 2 additionally needs 16-byte aligned x / x2 (the general kernel ignores the table area in LDS)
     const bool planesOk = a.vec1 && (g->C2 == 0 || a.vec2);
     const int mode = !fast ? 0 : (p.mode == 2 && !planesOk) ? 0 : p.mode;
+    static const int wg_diag = getenv("SPRK_WG_DIAG") ? atoi(getenv("SPRK_WG_DIAG")) : 0;
+    a.diag = wg_diag;
     a.nG1 = p.nG1;
     a.nG2 = p.nG2;
     dim3 grid(p.groups, p.nChunks, p.nblkN);
