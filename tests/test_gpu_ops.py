@@ -143,6 +143,11 @@ WINO_CASES = [
     ("wino+wgrad shift 96+1->96 @64", 128, 96, 1, 64, 64, 96, (2, 0, 1, 1), 1, True, False, True),
     ("wino+wgrad shift 96+48->96 @32x128", 128, 96, 48, 32, 128, 96, (2, 0, 1, 1), 1, True, True, True),
     ("wino+wgrad plain 48+10->88 @16x256 pad(1,1,2,0)", 130, 48, 10, 16, 256, 88, (1, 1, 2, 0), 0, True, False, True),
+    # the backward-weight kernel's border masks: two region columns (first / last only), one column (first and last),
+    # two region rows
+    ("wino+wgrad shift 96->96 @32x32 (two region columns)", 128, 96, 0, 32, 32, 96, (2, 0, 1, 1), 1, True, True, True),
+    ("wino+wgrad plain 48->96 @64x16 (one region column)", 128, 48, 0, 64, 16, 96, (1, 1, 1, 1), 0, True, True, True),
+    ("wino+wgrad shift 96->88 @8x96 (two region rows)", 172, 96, 0, 8, 96, 88, (2, 0, 1, 1), 2, False, True, True),
 ]
 
 
