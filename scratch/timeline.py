@@ -19,7 +19,7 @@ def short(n):
         args = [("bf16" if t == "DF16b" else "f16" if t == "DF16_" else t[2:-1]) for t in re.findall(r"DF16b|DF16_|Li\d+E|Lb[01]E", rest.split("EEv")[0])]
         return n[m.end():m.end() + k] + "<" + ",".join(args) + ">"
     n = re.sub(r"\(anonymous namespace\)::", "", n); n = re.sub(r"^void ", "", n)
-    return re.sub(r"\(.*$", "", n)[:70]
+    return re.sub(r"\(.*$", "", n)[:int(os.environ.get("TL_NAME", "70"))]
 # step boundaries: the fused Adam kernels end a step
 adam = [i for i, r in enumerate(rows) if "FusedAdam" in r[0] or "adam_multi" in r[0]]
 ends = [i for j, i in enumerate(adam) if j + 1 == len(adam) or adam[j + 1] - i > 20]
