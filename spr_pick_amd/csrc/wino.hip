@@ -370,12 +370,14 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
             first_loads();
         }
 
-    // output transform.  E[pg][b][channel'][tile'] with tile' = lq + 4 r + 16 mt + 32 th; 32 channels a pass.
+    // output transform.  E[pg][b][channel'][tile]: an accumulator quad holds tiles 32 th + 16 mt + 4 lq + r, r = 0..3 —
+    // four consecutive floats of a channel row, ONE ds_write_b128 (the 8 lanes a 16-byte write serves per cycle are 8
+    // channels, 68 floats apart: 32 different banks; the first form wrote 4 x ds_write_b32 to a permuted tile index);
+    // 32 channels a pass.
     float *E = smem + 2 * UFLOATS + 2 * RAWF;
-    // reader lane -> tile (row rl_ty, column rl_tx) = tile index T = (rl_ty << LGTX) + rl_tx; its slot is
-    // tile' = lq + 4 r + 16 (T >> 4) with 4 lq + r = T & 15
+    // reader lane -> tile (row rl_ty, column rl_tx) = tile index T = (rl_ty << LGTX) + rl_tx = lane
     const int rl_tx = lane & ((1 << LGTX) - 1), rl_ty = lane >> LGTX;
-    const int tprime = ((lane & 15) >> 2) + 4 * (lane & 3) + 16 * (lane >> 4);
+    const int tprime = lane;
     // stores: a wave-uniform plane pointer (scalar arithmetic) + the lane's fixed byte offset inside the tile
     const int lane_off = a.up2 ? ((4 * rl_ty) * (2 * a.W) + 4 * rl_tx) * 4 : ((2 * rl_ty) * a.W + 2 * rl_tx) * 4;
     const long tile_org = a.up2 ? ((long)(2 * e_by * TR) * (2 * a.W) + 2 * e_bx * TC) : ((long)(e_by * TR) * a.W + e_bx * TC);
@@ -393,12 +395,9 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
                     // packed adds on the accumulator quads; same association as the scalar form
                     const f32x4 s0 = (acc[0][mt][nt] + acc[1][mt][nt]) + acc[2][mt][nt];
                     const f32x4 s1 = (acc[1][mt][nt] - acc[2][mt][nt]) - acc[3][mt][nt];
-                    float *e = E + ((pg * 2) * 32 + n2 * 16 + l15) * ETS + lq + 16 * mt + 32 * th;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        e[4 * r] = s0[r];
-                        e[32 * ETS + 4 * r] = s1[r];
-                    }
+                    float *e = E + ((pg * 2) * 32 + n2 * 16 + l15) * ETS + 4 * lq + 16 * mt + 32 * th;
+                    *reinterpret_cast<f32x4 *>(e) = s0;
+                    *reinterpret_cast<f32x4 *>(e + 32 * ETS) = s1;
                 }
             }
         }
