@@ -402,58 +402,74 @@ __global__ __launch_bounds__(kThreads, 1) void wino_conv_kernel(const KArgs a) {
             }
         }
         lds_barrier();   // LDS only: the next tile's first loads and the previous pass's stores stay in flight
+        // the reader in three forms picked once per pass (plain / masked by a fused activation backward / fused x2
+        // up-sampling stores) instead of run-time branches per channel; channel planes by pointer increments
+        auto reader = [&](auto modec) {
+            constexpr int MODE = decltype(modec)::value;   // 0 plain, 1 mask, 2 up2
+            const long ch0 = (long)e_n * a.Cout + grp * (NT * 16) + pass * 32 + wave;
+            const float *yc = uniform_ptr(a.y + ch0 * plane + tile_org);
+            const float *mc = MODE == 1 ? uniform_ptr(a.mask + ch0 * plane + tile_org) : nullptr;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int cp = wave + 8 * it;   // channel within the pass
-            const int co = grp * (NT * 16) + pass * 32 + cp;
-            if (pass * 32 + cp < NT * 16 && co < a.Cout) {
-                // mask of a fused activation backward: the saved activations at the output positions, fetched first
-                f32x2 mk0 = {1.f, 1.f}, mk1 = {1.f, 1.f};
-                if (a.mask) {
-                    const rsrc_t mr = make_rsrc(uniform_ptr(a.mask + ((long)e_n * a.Cout + co) * plane + tile_org));
-                    mk0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mr, lane_off, 0, 0));
-                    mk1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mr, lane_off, 4 * a.W, 0));
-                }
-                f32x2 s[4];
+            for (int it = 0; it < 4; ++it) {
+                const int cp = wave + 8 * it;   // channel within the pass
+                const int co = grp * (NT * 16) + pass * 32 + cp;
+                if (pass * 32 + cp < NT * 16 && co < a.Cout) {
+                    // mask of a fused activation backward: the saved activations at the output positions, fetched first
+                    f32x2 mk0 = {1.f, 1.f}, mk1 = {1.f, 1.f};
+                    if constexpr (MODE == 1) {
+                        const rsrc_t mr = make_rsrc(mc);
+                        mk0 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mr, lane_off, 0, 0));
+                        mk1 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mr, lane_off, 4 * a.W, 0));
+                    }
+                    f32x2 s[4];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    s[w][0] = E[((w * 2 + 0) * 32 + cp) * ETS + tprime];
-                    s[w][1] = E[((w * 2 + 1) * 32 + cp) * ETS + tprime];
+                    for (int w = 0; w < 4; ++w) {
+                        s[w][0] = E[((w * 2 + 0) * 32 + cp) * ETS + tprime];
+                        s[w][1] = E[((w * 2 + 1) * 32 + cp) * ETS + tprime];
+                    }
+                    const float sc = EC[pass * 32 + cp], sh = EC[96 + pass * 32 + cp];
+                    f32x2 o0 = ((s[0] + s[1]) + s[2]) * sc + sh;
+                    f32x2 o1 = ((s[1] - s[2]) - s[3]) * sc + sh;
+                    if (a.act == SPRK_ACT_LEAKY) {   // max(v, 0.1 v) = v > 0 ? v : 0.1 v
+                        o0 = __builtin_elementwise_max(o0, o0 * kLeak);
+                        o1 = __builtin_elementwise_max(o1, o1 * kLeak);
+                    } else if (a.act == SPRK_ACT_RELU) {
+                        o0 = __builtin_elementwise_max(o0, (f32x2){0.f, 0.f});
+                        o1 = __builtin_elementwise_max(o1, (f32x2){0.f, 0.f});
+                    }
+                    if constexpr (MODE == 1) {
+                        const float neg = a.mact == SPRK_ACT_LEAKY ? kLeak : 0.f;
+                        o0[0] *= mk0[0] > 0.f ? 1.f : neg;
+                        o0[1] *= mk0[1] > 0.f ? 1.f : neg;
+                        o1[0] *= mk1[0] > 0.f ? 1.f : neg;
+                        o1[1] *= mk1[1] > 0.f ? 1.f : neg;
+                    }
+                    // buffer stores: wave-uniform descriptor (plane + tile origin, scalar arithmetic), the lane's fixed
+                    // byte offset, the row stride in the scalar offset — no vector address arithmetic in the epilogue
+                    const rsrc_t yr = make_rsrc(yc);
+                    if constexpr (MODE == 2) {   // nearest x2 upsampling fused into the stores: each value to its 2x2 block
+                        const int W2b = 8 * a.W;
+                        const u32x4 r0 = {fbits(o0[0]), fbits(o0[0]), fbits(o0[1]), fbits(o0[1])},
+                                    r1 = {fbits(o1[0]), fbits(o1[0]), fbits(o1[1]), fbits(o1[1])};
+                        __builtin_amdgcn_raw_buffer_store_b128(r0, yr, lane_off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(r0, yr, lane_off, W2b, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(r1, yr, lane_off, 2 * W2b, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(r1, yr, lane_off, 3 * W2b, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){fbits(o0[0]), fbits(o0[1])}, yr, lane_off, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){fbits(o1[0]), fbits(o1[1])}, yr, lane_off, 4 * a.W, 0);
+                    }
                 }
-                const float sc = EC[pass * 32 + cp], sh = EC[96 + pass * 32 + cp];
-                f32x2 o0 = ((s[0] + s[1]) + s[2]) * sc + sh;
-                f32x2 o1 = ((s[1] - s[2]) - s[3]) * sc + sh;
-                if (a.act == SPRK_ACT_LEAKY) {   // max(v, 0.1 v) = v > 0 ? v : 0.1 v
-                    o0 = __builtin_elementwise_max(o0, o0 * kLeak);
-                    o1 = __builtin_elementwise_max(o1, o1 * kLeak);
-                } else if (a.act == SPRK_ACT_RELU) {
-                    o0 = __builtin_elementwise_max(o0, (f32x2){0.f, 0.f});
-                    o1 = __builtin_elementwise_max(o1, (f32x2){0.f, 0.f});
-                }
-                if (a.mask) {
-                    const float neg = a.mact == SPRK_ACT_LEAKY ? kLeak : 0.f;
-                    o0[0] *= mk0[0] > 0.f ? 1.f : neg;
-                    o0[1] *= mk0[1] > 0.f ? 1.f : neg;
-                    o1[0] *= mk1[0] > 0.f ? 1.f : neg;
-                    o1[1] *= mk1[1] > 0.f ? 1.f : neg;
-                }
-                // buffer stores: wave-uniform descriptor (plane + tile origin, scalar arithmetic), the lane's fixed byte
-                // offset, the row stride in the scalar offset — no vector address arithmetic in the epilogue
-                const rsrc_t yr = make_rsrc(uniform_ptr(a.y + ((long)e_n * a.Cout + co) * plane + tile_org));
-                if (a.up2) {   // nearest x2 upsampling fused into the stores: each value to its 2x2 block
-                    const int W2b = 8 * a.W;
-                    const u32x4 r0 = {fbits(o0[0]), fbits(o0[0]), fbits(o0[1]), fbits(o0[1])},
-                                r1 = {fbits(o1[0]), fbits(o1[0]), fbits(o1[1]), fbits(o1[1])};
-                    __builtin_amdgcn_raw_buffer_store_b128(r0, yr, lane_off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(r0, yr, lane_off, W2b, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(r1, yr, lane_off, 2 * W2b, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(r1, yr, lane_off, 3 * W2b, 0);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){fbits(o0[0]), fbits(o0[1])}, yr, lane_off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64((u32x2){fbits(o1[0]), fbits(o1[1])}, yr, lane_off, 4 * a.W, 0);
-                }
+                yc += 8 * plane;
+                if constexpr (MODE == 1) mc += 8 * plane;
             }
-        }
+        };
+        if (a.up2)
+            reader(IC<2>{});
+        else if (a.mask)
+            reader(IC<1>{});
+        else
+            reader(IC<0>{});
         lds_barrier();
     }
 #ifdef WINO_STAMP
