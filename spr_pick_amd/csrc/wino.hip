@@ -626,8 +626,11 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a
     }
     asm volatile("" : "+v"(baseA[0]), "+v"(baseA[1]), "+v"(baseB2[0]), "+v"(baseB2[1]), "+v"(baseB[0]), "+v"(baseB[1]));
 
-    auto kstep = [&](auto stage, auto kstp) {
+    // zm: the wave mixes two gradient rows (pg 1, 2) or takes one (pg 0, 3) — a compile-time property of each copy of
+    // the region loop (a run-time branch per channel tile and k-step cost 12 taken branches per region)
+    auto kstep = [&](auto stage, auto kstp, auto zm) {
         constexpr int S = decltype(stage)::value, ks = decltype(kstp)::value;
+        constexpr bool ZMIX = decltype(zm)::value != 0;
         constexpr int trow = ks >> 1, tcol = 8 * (ks & 1);   // tiles 4 ks .. 4 ks + 3: tile row, first column
         const lds_cfp pa = lds_f(baseA[S]), pb = lds_f(baseB2[S]), pz = lds_f(baseB[S]);
         // Both transforms in PACKED fp32 (v_pk_fma_f32 / v_pk_add_f32 on the register pairs ds_read2_b32 returns, with
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a
         for (int nt = 0; nt < 3; ++nt) {
             const int o = nt * 16 + 2 * trow * 48 + tcol;
             f32x2 z = {pz[o], pz[o + 1]};
-            if (zmix) z = __builtin_elementwise_fma((f32x2){pz[o + 48], pz[o + 48 + 1]}, zs2, z);
+            if constexpr (ZMIX) z = __builtin_elementwise_fma((f32x2){pz[o + 48], pz[o + 48 + 1]}, zs2, z);
             f32x2 b12;
             // (z0 + z1, z1 - z0): the second is -(z0 - z1)
             asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(b12) : "v"(z), "v"(z));
@@ -673,25 +676,35 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a
                 for (int nt = 0; nt < 3; ++nt)
                     acc[p][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][p], bv[nt][p], acc[p][mt][nt], 0, 0, 0);
     };
-    auto stage_body = [&](auto stage, int region) {
+    auto stage_body = [&](auto stage, int region, auto zm) {
         constexpr int S = decltype(stage)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (region + (int)gridDim.x < nregions) issue(smem + (1 - S) * WSTAGE);
         // (no scheduling fences between the k-steps any more: with the packed transforms the kernel has 186 VGPRs and no
         // spills, and the compiler may run a k-step's LDS reads under the previous one's MFMAs: 446.5 -> 442 us)
-        kstep(stage, IC<0>{});
-        kstep(stage, IC<1>{});
-        kstep(stage, IC<2>{});
-        kstep(stage, IC<3>{});
+        // fences between the k-steps: without the old per-tile branches a region is one basic block of 144 MFMAs, and the
+        // scheduler hoists so many LDS reads that the kernel needs 256 registers and scratch
+        kstep(stage, IC<0>{}, zm);
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(stage, IC<1>{}, zm);
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(stage, IC<2>{}, zm);
+        __builtin_amdgcn_sched_barrier(0);
+        kstep(stage, IC<3>{}, zm);
     };
 
     int region = xcd_slot(blockIdx.x, gridDim.x, a.xcd);
     if (region < nregions) issue(smem);
-    for (; region < nregions; region += 2 * gridDim.x) {
-        stage_body(IC<0>{}, region);
-        if (region + (int)gridDim.x < nregions) stage_body(IC<1>{}, region + gridDim.x);
-    }
+    auto regions = [&](auto zm) {
+        for (; region < nregions; region += 2 * gridDim.x) {
+            stage_body(IC<0>{}, region, zm);
+            if (region + (int)gridDim.x < nregions) stage_body(IC<1>{}, region + gridDim.x, zm);
+        }
+    };
+    // both copies run to the end of the kernel (a join after the loop made the compiler shuffle the 144 accumulator
+    // registers through scratch)
+    auto finish = [&]() {
     __syncthreads();
 
     // final transform dW = G^T M G: column pass (over p) in registers, row pass (over pg) through LDS.
@@ -728,6 +741,14 @@ __global__ __launch_bounds__(kThreads, 1) void wino_wgrad_kernel(const WgKArgs a
             }
         }
         __syncthreads();
+    }
+    };
+    if (zmix) {
+        regions(IC<1>{});
+        finish();
+    } else {
+        regions(IC<0>{});
+        finish();
     }
 }
 
