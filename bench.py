@@ -4,7 +4,9 @@
 plus the inference legs (filled whole-micrograph forward + NMS, Mpix/s; configs[2] is the 4096^2 one).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (RANK /
+  WORLD_SIZE in the environment), or started bare: the parent then — before anything touches the GPU — starts that very
+  launcher as a child, relays rank 0's JSON line and exits with the child's code (self_launch).
 
 One step = zero_grad -> Denoiser.run_pipeline(train) (2 JointNetwork passes + sigma net + losses)
 -> backward -> [flat gradient all-reduce over RCCL] -> Adam.  Batches are resident in HBM before the
@@ -267,6 +269,70 @@ def inference_leg(den, dev, size, reps, keep_picks=None):
                             "(includes the D2H of the picks)"}}
 
 
+def self_launch(gpus):
+    """`python bench.py --gpus N` without a launcher around it: start `torch.distributed.run` with N ranks of this script
+    as a CHILD process (this process has not touched the GPU and never will: no exec, nothing to tear down), pass its
+    stdout (rank 0's JSON line) and stderr through, return its exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: %s" % " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, env=env)
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        return proc.wait()
+
+
+def stub_main(args):
+    """SPRK_BENCH_STUB=1 (tests/test_bench_launch_cpu.py): the launch / timing / reporting skeleton of main() with a
+    stand-in step (a small all-reduce + a sleep) instead of the GPU step — rendezvous, barrier-bracketed timed region,
+    max over ranks, one JSON line from rank 0, non-zero exit when a rank fails; runs on CPU under gloo."""
+    import torch.distributed as dist
+    from spr_pick_amd import distributed
+    rank, world, _ = distributed.init_from_env()
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+    if os.environ["SPRK_BENCH_STUB"] == "fail%d" % rank:
+        raise RuntimeError("stub: rank %d fails on purpose" % rank)
+    batch = args.global_batch // world if args.global_batch else args.batch
+    buf = torch.ones(1024)
+
+    def step():
+        if world > 1:
+            dist.all_reduce(buf)
+            buf.div_(world)
+        time.sleep(0.002 * (1 + rank))            # ranks differ: the report must carry the slowest
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt)
+    if rank == 0:
+        print(json.dumps({"metric": "train_patches_per_sec", "value": world * batch * args.steps / dt, "unit": "patches/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak", "vs_baseline": None,
+                          "dtype": "stub", "data": "none (SPRK_BENCH_STUB)", "config": {"workload": "stub", "per_gpu_batch": batch,
+                                                                                      "global_batch": batch * world}}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -289,16 +355,26 @@ def main():
                     help="also time the step at 16 patches per GPU (BASELINE configs[3]'s per-GPU batch)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-pipeline", choices=("on", "off"), default="on",
+                    help="BASELINE configs[4] in small through the `joint` CLI (full_pipeline.py): train on a synthetic set on "
+                         "disk, evaluate the final weights, recall / precision of the picks against the planted particles")
+    ap.add_argument("--full-pipeline-args", default="--micrographs 32 --iterations 96000 --batch 16 --dtypes f32,mixed16 "
+                                                    "--agreement f16 --print-interval 9600")
     ap.add_argument("--infer-size", type=int, default=1024, help="side of the small inference micrograph (0 = skip)")
     ap.add_argument("--infer-large", type=int, default=4096, help="side of the configs[2] micrograph (0 = skip)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if os.environ.get("SPRK_BENCH_STUB"):
+        return stub_main(args)
 
     from spr_pick_amd import Denoiser, _lib, distributed, graph_step, synthetic
     from spr_pick_amd.params import PipelineOutput as P
     import torch.distributed as dist
 
     rank, world, local = distributed.init_from_env()
-    assert world == args.gpus, "launch with --nproc-per-node == --gpus (WORLD_SIZE=%d, --gpus %d)" % (world, args.gpus)
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d (a launcher with another --nproc-per-node is around this run)" % (
+        world, args.gpus)
     local = local % torch.cuda.device_count()   # (== LOCAL_RANK on a real multi-GPU node)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -557,6 +633,17 @@ def main():
         den.set_conv_dtype(args.dtype)
 
     log("batch-16 leg done")
+    # the last collective is behind us: every rank leaves the process group NOW, together (a rank that tears RCCL down while
+    # rank 0 is still busy with the single-GPU legs would leave rank 0's own teardown waiting for peers that are gone)
+    parallelism = ("dp%d (in-place flat fp32 gradient all-reduce over %s, %d floats%s)" % (
+                       world, distributed.backend_name(), stepper.grads.live_numel,
+                       "; forced 1-rank collective" if world == 1 else "")
+                   if stepper.grads.collectives else "single GPU")
+    fence()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     infer = infer_large = None
     if rank == 0:
         del o
@@ -584,10 +671,6 @@ def main():
                     "|A & B| / |A | B| of the coordinate sets after NMS: same micrograph, same reparameterisation noise, fp16 "
                     "vs fp32 MFMA operands in the U-Nets")
 
-    if rank != 0:
-        if dist.is_initialized():
-            dist.destroy_process_group()
-        return
     patches = world * batch * args.steps
     value = patches / dt
     nm, gain, note = KCLASS[DOM]
@@ -614,16 +697,17 @@ def main():
         "metric": "train_patches_per_sec", "value": value, "unit": "patches/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: ssdn --noise_style gaussian --noise_value var, joint mode, "
+        "config": {"workload": "%s: ssdn --noise_style gaussian --noise_value var, joint mode, "
                                "64x64 patches from 4 synthetic 1024x1024 micrographs, batch %d per GPU, alpha 0.75, "
-                               "tau 0.01, Adam; %s" % (batch, "fp32 MFMA convolutions (Winograd F(2x2,3x3) for the wide 3x3 layers)"
+                               "tau 0.01, Adam; %s" % (
+                                   "BASELINE configs[3] (global batch %d over %d GPUs, data-parallel, RCCL gradient all-reduce)" % (
+                                       batch * world, world) if (args.global_batch and world > 1) else
+                                   ("BASELINE configs[1] per GPU, weak scaling over %d GPUs" % world if world > 1 else
+                                    "BASELINE configs[1]"), batch, "fp32 MFMA convolutions (Winograd F(2x2,3x3) for the wide 3x3 layers)"
                                                     if args.dtype == "f32" else
                                                     "%s-operand MFMA convolutions in the U-Nets where faster, fp32 elsewhere" % args.dtype),
                    "per_gpu_batch": batch, "global_batch": batch * world, "patch": 64,
-                   "parallelism": "dp%d (in-place flat fp32 gradient all-reduce over %s, %d floats%s)" % (
-                                      world, distributed.backend_name(), stepper.grads.live_numel,
-                                      "; forced 1-rank collective" if world == 1 else "")
-                                  if stepper.grads.collectives else "single GPU",
+                   "parallelism": parallelism,
                    "execution": ("forward+backward replayed from 2 HIP graphs (one per flip axis, %d kernels each), eager "
                                  "all-reduce + one-launch Adam (sprk_adam_multi)" % (stepper.kernels_per_step or 0)) if use_graph
                                 else "every launch enqueued from Python (--graph off)"},
@@ -671,17 +755,31 @@ def main():
         out["inference"] = infer
     if infer_large:
         out["inference_large"] = infer_large
+    if world == 1 and args.full_pipeline == "on":
+        # the whole workflow through the CLI, with the trainer's own loop (device patch feed, sampler, logging, checkpoints)
+        # and the evaluator's (file reading, PNG / score writers): what a user of `joint train start` / `joint eval` gets
+        import full_pipeline
+        del stepper, opt, den
+        torch.cuda.empty_cache()
+        fp = full_pipeline.main(args.full_pipeline_args.split(), quiet=True)
+        for r in fp["runs"].values():
+            b = r["train"]["batch"]
+            resident = {32: value_of, 16: {k: v["value"] for k, v in (b16 or {}).items()}}.get(b, {})
+            key = {"mixed16": "bf16"}.get(r["dtype"], r["dtype"])
+            if resident.get(key):
+                r["train"]["resident_batch_patches_per_s"] = resident[key]
+                r["train"]["trainer_loop_vs_resident_batches"] = r["train"]["trainer_loop_patches_per_s"] / resident[key]
+        out["full_pipeline"] = fp
+        log("full pipeline leg done")
     log("GPU legs done")
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:       # rank 0, after the last barrier; at N > 1 too (the other ranks have left)
         out["cpu_baseline"] = cpu_baseline(mics, args.cpu_seconds)
         log("CPU training baseline done")
         out["vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         if args.infer_size:
             out["cpu_baseline"]["inference"] = cpu_inference_baseline(args.infer_size)
             out["inference"]["vs_cpu_baseline"] = infer["value"] / out["cpu_baseline"]["inference"]["value"]
-    print(json.dumps(out))
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -96,7 +96,7 @@ typedef struct sprk_conv_epilogue {
  * entry points exist).  A binding must refuse a library whose sprk_version() differs from the header it was
  * written against, and may compare sprk_struct_bytes(0 | 1 | 2) with its own sizeof(sprk_conv_geom |
  * sprk_conv_epilogue | sprk_reduce_item). */
-#define SPRK_ABI_VERSION 300
+#define SPRK_ABI_VERSION 400
 const char *sprk_last_error(void);
 int sprk_version(void);
 size_t sprk_struct_bytes(int which);
@@ -164,8 +164,12 @@ int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, flo
  *      the transform that call would run (no launch; item->kind == 0: that path has none);
  *   2. after every weight update: sprk_prepare_weights(items, n) — all transforms in one launch per 40 items;
  *   3. the convolution calls pass the same workspace and SPRK_DT_WPREP in dtype: the transform launch is skipped.
- * Same device code either way: results are bit-identical to the plain calls.  The items are opaque. */
+ * Same device code either way: results are bit-identical to the plain calls.  The items are opaque.
+ * A SPRK_DT_WPREP call may add SPRK_DT_WPREP_KIND(item.kind): the library then checks that the kernel path the call takes
+ * reads a transform of that kind and returns SPRK_EINVAL otherwise (instead of reading a slab in another layout). */
 #define SPRK_DT_WPREP 0x800
+#define SPRK_DT_WPREP_KIND(kind) (((kind) & 7) << 12)
+#define SPRK_DT_WPREP_KIND_OF(dtype) (((dtype) >> 12) & 7)
 typedef struct sprk_wprep_item {
     const float *w;
     void *dst;
@@ -295,19 +299,23 @@ typedef struct sprk_adam_item {
 int sprk_adam_multi(const sprk_adam_item *items, const int *start, int n_items, int n_blocks,
                     const float *lr, const float *step_in, float *step_out,
                     float beta1, float beta2, float eps, void *stream);
-/* SSDN gaussian likelihood + posterior mean (denoiser_v2.py:449-462, :514):
- *   var_x = A^2, var_n = s^2, var_y = var_x + var_n
+/* SSDN likelihood + posterior mean (denoiser_v2.py:405-424 noise model, :449-462 likelihood, :514 mean):
+ *   var_x = A^2, var_y = var_x + var_n
+ *   style SPRK_NOISE_GAUSSIAN: s = noise_std[b],                       var_n = s^2
+ *   style SPRK_NOISE_POISSON : s = sqrt(max(mu, 1e-3) * noise_std[b]), var_n = s^2   (per pixel; Hasinoff 2012)
  *   nll = (x-mu)^2/var_y + log var_y - 0.05 s      -> loss[b] = mean over HW
  *   pme = (x var_x + mu var_n)/var_y ;  model_std = sqrt(var_x)
- * x [B,1,HW], out_stats [B,2,HW], noise_std [B]; pme/model_std [B,HW]; loss [B].
+ * x [B,1,HW], out_stats [B,2,HW], noise_std [B] (the remapped estimate softplus(.-4)+1e-3);
+ * pme/model_std [B,HW] (may be null); noise_std_map [B,HW]: s per pixel, written for POISSON only (may be null); loss [B].
  * ws: B*nblk floats of partial sums. */
+enum { SPRK_NOISE_GAUSSIAN = 0, SPRK_NOISE_POISSON = 1 };
 size_t sprk_ssdn_ws_bytes(int B, int HW);
 int sprk_ssdn_fwd(const float *x, const float *out_stats, const float *noise_std,
-                  float *loss, float *pme, float *model_std, int B, int HW,
+                  float *loss, float *pme, float *model_std, float *noise_std_map, int style, int B, int HW,
                   void *ws, size_t ws_bytes, void *stream);
-/* gloss [B] = d L / d loss[b];  g_out_stats [B,2,HW] (overwritten), g_noise_std [B] */
+/* gloss [B] = d L / d loss[b];  g_out_stats [B,2,HW] (overwritten), g_noise_std [B] (d L / d noise_std[b]) */
 int sprk_ssdn_bwd(const float *gloss, const float *x, const float *out_stats, const float *noise_std,
-                  float *g_out_stats, float *g_noise_std, int B, int HW,
+                  float *g_out_stats, float *g_noise_std, int style, int B, int HW,
                   void *ws, size_t ws_bytes, void *stream);
 
 /* ---- training-patch feed ----------------------------------------------------------------

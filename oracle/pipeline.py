@@ -8,8 +8,8 @@ Reference behaviour restated (file:line under /root/reference/spr_pick):
   Denoiser._ssdn_pipeline     denoiser_v2.py:598-849   (mode="denoise")
   pu_loss / PuLoss            utils/losses.py:303-349  (slack=4.0 via PuLoss.forward)
   compute_ramped_lrate        utils/utils.py:50-69; as called at train.py:434-441
-Only the 1-channel, gaussian, ``--noise_value var`` branch is restated — the one
-BASELINE.json's configs run.
+The 1-channel, ``--noise_value var`` branch is restated, with the gaussian likelihood (the one
+BASELINE.json's configs run) and the poisson one (denoiser_v2.py:412-424).
 """
 import numpy as np
 import torch
@@ -53,17 +53,21 @@ def noise_std_from_sigma_net(sd, x):
     return F.softplus(y - 4.0) + 1e-3
 
 
-def ssdn_terms(x, mu, a, noise_std):
+def ssdn_terms(x, mu, a, noise_std, noise_style="gaussian"):
+    """noise_std: the remapped estimate softplus(.-4)+1e-3, [B,1,1,1].  gaussian: that IS the noise std;
+    poisson (denoiser_v2.py:412-424, unknown parameter): std = sqrt(max(mu, 1e-3) * estimate), per pixel."""
+    if noise_style.startswith("poisson"):
+        noise_std = (torch.maximum(mu, torch.tensor(1e-3, dtype=mu.dtype)) * noise_std) ** 0.5
     sigma_x = a ** 2
     sigma_n = noise_std ** 2
     sigma_y = sigma_x + sigma_n
     nll = (x - mu) ** 2 / sigma_y + torch.log(sigma_y) - 0.05 * noise_std
     pme = (x * sigma_x + mu * sigma_n) / (sigma_x + sigma_n)
-    return nll, pme, sigma_x
+    return nll, pme, sigma_x, noise_std
 
 
 def joint_pipeline(sd, inp, target, alpha, tau, train, eps, eps_flip=None, flip_p=None,
-                   filled=None, taps=None):
+                   filled=None, taps=None, noise_style="gaussian"):
     """Denoiser._new_pipeline.  ``sd`` has keys with prefixes MODEL / SIGMA.
 
     eps / eps_flip: the N(0,1) draws of the two JointNetwork passes;
@@ -81,7 +85,7 @@ def joint_pipeline(sd, inp, target, alpha, tau, train, eps, eps_flip=None, flip_
         pred = pu_loss(tau, p, target)
     mu, a = out[:, 0:1], out[:, 1:2]
     noise_std = noise_std_from_sigma_net(sd, inp)
-    nll, pme, sigma_x = ssdn_terms(inp, mu, a, noise_std)
+    nll, pme, sigma_x, noise_std = ssdn_terms(inp, mu, a, noise_std, noise_style)
     nll = nll.reshape(nll.shape[0], -1).mean(1, keepdim=True)
     if train:
         consis = F.mse_loss(p, p_f)
@@ -100,7 +104,7 @@ def ssdn_pipeline(sd, inp):
     out = networks.unet_blindspot(sd, MODEL + "denoise_branch.", inp)
     mu, a = out[:, 0:1], out[:, 1:2]
     noise_std = noise_std_from_sigma_net(sd, inp)
-    nll, pme, sigma_x = ssdn_terms(inp, mu, a, noise_std)
+    nll, pme, sigma_x, noise_std = ssdn_terms(inp, mu, a, noise_std)
     nll = nll.reshape(nll.shape[0], -1).mean(1, keepdim=True)
     return dict(LOSS=nll, IMG_MU=mu, IMG_DENOISED=pme, NOISE_STD_DEV=noise_std[:, 0],
                 MODEL_STD_DEV=(sigma_x ** 0.5)[:, 0].unsqueeze(0))

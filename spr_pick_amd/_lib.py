@@ -93,8 +93,8 @@ _SIGS = {
     "sprk_sigmoid_clamp_fwd": (c_i, [c_f, c_f, ctypes.c_long, c_vp]),
     "sprk_sigmoid_clamp_bwd": (c_i, [c_f, c_f, c_f, ctypes.c_long, c_vp]),
     "sprk_ssdn_ws_bytes": (c_sz, [c_i, c_i]),
-    "sprk_ssdn_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_vp, c_sz, c_vp]),
-    "sprk_ssdn_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_vp, c_sz, c_vp]),
+    "sprk_ssdn_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "sprk_ssdn_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "sprk_nms2d_ws_bytes": (c_sz, [c_i, c_i, c_i]),
     "sprk_nms2d": (c_i, [c_f, c_i, c_i, c_i, ctypes.c_float, c_f, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
     "sprk_gather_patches": (c_i, [c_vp, c_i, c_vp, c_vp, c_vp, c_f, c_i, c_i, c_i, c_vp]),
@@ -105,7 +105,7 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 300          # SPRK_ABI_VERSION of the include/sprk.h these signatures were written against
+ABI_VERSION = 400          # SPRK_ABI_VERSION of the include/sprk.h these signatures were written against
 _lib = None
 
 

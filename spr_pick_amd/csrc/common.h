@@ -85,6 +85,18 @@ __device__ __forceinline__ int xcd_slot(int id, int nwg, int on) {
     return (id & 7) * (nwg >> 3) + (id >> 3);
 }
 namespace sprk {
+// Timing experiments that switch phases of a kernel OFF (the results are then wrong on purpose: SPRK_WG_DIAG,
+// SPRK_C16_DIAG, SPRK_NMS_DIAG, SPRK_WINO_DIAG).  They exist only in a library built with -DSPRK_DIAG
+// (make DIAG=1); the shipped libsprk.so ignores the variables, so an inherited environment cannot corrupt a run.
+inline int diag_env(const char *name) {
+#ifdef SPRK_DIAG
+    const char *v = getenv(name);
+    return v ? atoi(v) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
+}
 inline int xcd_on() {
     static const int on = getenv("SPRK_XCD") ? atoi(getenv("SPRK_XCD")) : 1;   // debug: 0 = plain round-robin order
     return on;

@@ -1351,15 +1351,15 @@ static int conv2d_fwd_impl(const float *x, const float *x2, const float *w, floa
 
 int sprk_conv2d_fwd(const float *x, const float *x2, const float *w, float *y, const sprk_conv_geom *g,
                     const sprk_conv_epilogue *ep, void *ws, size_t ws_bytes, void *stream) {
-    sprk::WprepScope scope(nullptr, g && (g->dtype & SPRK_DT_WPREP));
-    return conv2d_fwd_impl(x, x2, w, y, g, ep, ws, ws_bytes, stream);
+    sprk::WprepScope scope(nullptr, g ? g->dtype : 0);
+    return scope.verify(conv2d_fwd_impl(x, x2, w, y, g, ep, ws, ws_bytes, stream));
 }
 
 int sprk_conv2d_fwd_wprep(const float *w, const sprk_conv_geom *g, const sprk_conv_epilogue *ep, void *ws,
                           size_t ws_bytes, sprk_wprep_item *item) {
     SPRK_REQUIRE(item && w && ws, "conv2d_fwd_wprep: null argument");
     *item = sprk_wprep_item{};
-    sprk::WprepScope scope(item, false);
+    sprk::WprepScope scope(item, 0);
     // the tensors are never touched in describe mode: the call ends at its weight-transform site
     const float *dummy = (const float *)ws;
     const int rc = conv2d_fwd_impl(dummy, g && g->C2 ? dummy : nullptr, w, (float *)ws, g, ep, ws, ws_bytes, nullptr);
@@ -1455,14 +1455,14 @@ static int conv2d_bwd_data_impl(const float *gy, const float *w, float *gin, con
 
 int sprk_conv2d_bwd_data_masked(const float *gy, const float *w, float *gin, const sprk_conv_geom *g,
                                 const float *mask_y, int mask_act, void *ws, size_t ws_bytes, void *stream) {
-    sprk::WprepScope scope(nullptr, g && (g->dtype & SPRK_DT_WPREP));
-    return conv2d_bwd_data_impl(gy, w, gin, g, mask_y, mask_act, ws, ws_bytes, stream);
+    sprk::WprepScope scope(nullptr, g ? g->dtype : 0);
+    return scope.verify(conv2d_bwd_data_impl(gy, w, gin, g, mask_y, mask_act, ws, ws_bytes, stream));
 }
 
 int sprk_conv2d_bwd_data_wprep(const float *w, const sprk_conv_geom *g, void *ws, size_t ws_bytes, sprk_wprep_item *item) {
     SPRK_REQUIRE(item && w && ws, "conv2d_bwd_data_wprep: null argument");
     *item = sprk_wprep_item{};
-    sprk::WprepScope scope(item, false);
+    sprk::WprepScope scope(item, 0);
     const int rc = conv2d_bwd_data_impl((const float *)ws, w, (float *)ws, g, nullptr, SPRK_ACT_NONE, ws, ws_bytes, nullptr);
     return rc == sprk::kWprepDescribed ? (int)SPRK_OK : rc;
 }
@@ -1633,7 +1633,7 @@ int sprk_conv2d_bwd_weight_partial(const float *x, const float *x2, const float 
     // MODE 2 additionally needs 16-byte aligned x / x2 (the general kernel ignores the table area in LDS)
     const bool planesOk = a.vec1 && (g->C2 == 0 || a.vec2);
     const int mode = !fast ? 0 : (p.mode == 2 && !planesOk) ? 0 : p.mode;
-    static const int wg_diag = getenv("SPRK_WG_DIAG") ? atoi(getenv("SPRK_WG_DIAG")) : 0;
+    static const int wg_diag = sprk::diag_env("SPRK_WG_DIAG");
     a.diag = wg_diag;
     a.nG1 = p.nG1;
     a.nG2 = p.nG2;

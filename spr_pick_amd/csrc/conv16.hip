@@ -883,7 +883,7 @@ static int run_tile(const Conv16Call &c, const PlanT &p, const float *x, const f
     k.ngLast = 9 * k.c8Last;
     k.PX = p.PX; k.PXP = p.PXP; k.inRows = p.inRows; k.inCols = p.inCols;
     k.ntiles = p.imgGroups * p.tilesX * p.tilesY;
-    static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
+    static const int diag = sprk::diag_env("SPRK_C16_DIAG");
     k.diag = diag;
     prof_begin(c.kclass, c.flops, s);
     prof_bytes(4.0 * c.N * ((double)(c.C1 + c.C2) * c.Hin * c.Win + (double)c.Cout * c.Hout * c.Wout * (c.up2 ? 4 : 1)));
@@ -983,7 +983,7 @@ int conv16_run(const Conv16Call &c, const float *x, const float *x2, const float
     k.ckeLast = Cin - (p.nchunks - 1) * p.CK;
     k.c8Last = cdiv(k.ckeLast, 8);
     k.ngLast = KHW * k.c8Last;
-    static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
+    static const int diag = sprk::diag_env("SPRK_C16_DIAG");
     k.diag = diag;
     prof_begin(c.kclass, c.flops, s);
     prof_bytes(4.0 * c.N * ((double)(c.C1 + c.C2) * c.Hin * c.Win + (double)c.Cout * c.Hout * c.Wout * (c.up2 ? 4 : 1)));

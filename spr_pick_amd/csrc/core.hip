@@ -233,13 +233,25 @@ int wprep_launch(const sprk_wprep_item *items, int n, hipStream_t s) {
 
 static thread_local sprk_wprep_item *t_wprep_describe = nullptr;
 static thread_local bool t_wprep_skip = false;
-WprepScope::WprepScope(sprk_wprep_item *describe, bool skip) {
+static thread_local int t_wprep_expect = 0, t_wprep_seen = 0;
+WprepScope::WprepScope(sprk_wprep_item *describe, int dtype) {
     t_wprep_describe = describe;
-    t_wprep_skip = skip;
+    t_wprep_skip = !describe && (dtype & SPRK_DT_WPREP);
+    t_wprep_expect = t_wprep_skip ? SPRK_DT_WPREP_KIND_OF(dtype) : 0;
+    t_wprep_seen = 0;
 }
 WprepScope::~WprepScope() {
     t_wprep_describe = nullptr;
     t_wprep_skip = false;
+    t_wprep_expect = t_wprep_seen = 0;
+}
+// A SPRK_DT_WPREP call that says which transform its workspace holds (SPRK_DT_WPREP_KIND) must reach a site that
+// would have produced exactly that kind: a path choice that differs from the describe call would read a slab in
+// another layout.
+int WprepScope::verify(int rc) const {
+    if (rc != SPRK_OK || !t_wprep_skip || !t_wprep_expect || t_wprep_seen == t_wprep_expect) return rc;
+    set_error("prepared weights: the workspace holds a transform of another kind than this call's kernel path reads");
+    return SPRK_EINVAL;
 }
 bool wprep_describing() { return t_wprep_describe != nullptr; }
 int wprep_site(const sprk_wprep_item &it, hipStream_t s) {
@@ -247,7 +259,14 @@ int wprep_site(const sprk_wprep_item &it, hipStream_t s) {
         *t_wprep_describe = it;
         return kWprepDescribed;
     }
-    if (t_wprep_skip) return SPRK_OK;
+    if (t_wprep_skip) {
+        t_wprep_seen = it.kind;
+        if (t_wprep_expect && it.kind != t_wprep_expect) {
+            set_error("prepared weights: the workspace holds a transform of another kind than this call's kernel path reads");
+            return SPRK_EINVAL;
+        }
+        return SPRK_OK;
+    }
     return wprep_launch(&it, 1, s);
 }
 

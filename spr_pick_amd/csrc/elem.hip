@@ -452,21 +452,34 @@ __global__ __launch_bounds__(kSsdnBlk) void pu_loss_kernel(const float *__restri
     }
 }
 
-// grid (nblk, B); partial[b*nblk + blk] = sum of nll over the block's pixels
+// grid (nblk, B); partial[b*nblk + blk] = sum of nll over the block's pixels.
+// POISSON (denoiser_v2.py:412-424): ns[b] is the remapped estimate e, the noise variance is signal dependent,
+// var_n = max(mu, 1e-3) * e per pixel, and the regulariser -0.05 * sqrt(var_n) is per pixel too.
+template <bool POISSON>
 __global__ __launch_bounds__(kSsdnBlk) void ssdn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ o,
                                                             const float *__restrict__ ns, float *__restrict__ partial,
-                                                            float *__restrict__ pme, float *__restrict__ mstd, int HW) {
+                                                            float *__restrict__ pme, float *__restrict__ mstd,
+                                                            float *__restrict__ nsmap, int HW) {
     __shared__ float red[kSsdnBlk];
     const int b = blockIdx.y;
-    const float s = ns[b], vn = s * s;
+    const float e = ns[b];
     float acc = 0.f;
     for (int i = blockIdx.x * kSsdnBlk + threadIdx.x; i < HW; i += gridDim.x * kSsdnBlk) {
         const float xv = x[(long)b * HW + i];
         const float mu = o[(long)(2 * b) * HW + i], a = o[(long)(2 * b + 1) * HW + i];
+        float s, vn;
+        if (POISSON) {
+            s = sqrtf(fmaxf(mu, 1e-3f) * e);
+            vn = s * s;                                 // the reference squares the root again (noise_std ** 2)
+        } else {
+            s = e;
+            vn = s * s;
+        }
         const float vx = a * a, vy = vx + vn, dd = xv - mu;
         acc += dd * dd / vy + logf(vy) - 0.05f * s;
         if (pme) pme[(long)b * HW + i] = (xv * vx + mu * vn) / (vx + vn);
         if (mstd) mstd[(long)b * HW + i] = sqrtf(vx);
+        if (POISSON && nsmap) nsmap[(long)b * HW + i] = s;
     }
     const float tot = block_sum(acc, red);
     if (threadIdx.x == 0) partial[b * gridDim.x + blockIdx.x] = tot;
@@ -481,22 +494,37 @@ __global__ void ssdn_finish_kernel(const float *__restrict__ partial, float *__r
     out[b] = s * scale;
 }
 
+template <bool POISSON>
 __global__ __launch_bounds__(kSsdnBlk) void ssdn_bwd_kernel(const float *__restrict__ gl, const float *__restrict__ x,
                                                             const float *__restrict__ o, const float *__restrict__ ns,
                                                             float *__restrict__ go, float *__restrict__ partial, int HW) {
     __shared__ float red[kSsdnBlk];
     const int b = blockIdx.y;
-    const float s = ns[b], vn = s * s;
+    const float e = ns[b];
     const float g = gl[b] / (float)HW;
     float acc = 0.f;
     for (int i = blockIdx.x * kSsdnBlk + threadIdx.x; i < HW; i += gridDim.x * kSsdnBlk) {
         const float xv = x[(long)b * HW + i];
         const float mu = o[(long)(2 * b) * HW + i], a = o[(long)(2 * b + 1) * HW + i];
-        const float vy = a * a + vn, dd = xv - mu;
-        const float dvy = 1.f / vy - dd * dd / (vy * vy);  // d nll / d var_y
-        go[(long)(2 * b) * HW + i] = g * (-2.f * dd / vy);
-        go[(long)(2 * b + 1) * HW + i] = g * dvy * 2.f * a;
-        acc += dvy * 2.f * s - 0.05f;
+        if (POISSON) {
+            const float m = fmaxf(mu, 1e-3f);
+            const float s = sqrtf(m * e), vn = s * s;
+            const float vy = a * a + vn, dd = xv - mu;
+            const float dvy = 1.f / vy - dd * dd / (vy * vy);  // d nll / d var_y
+            const float gvn = dvy * 2.f * s * (0.5f / s) - 0.05f * (0.5f / s);   // through var_n = s^2 and through -0.05 s
+            // torch.maximum hands the gradient to mu above the floor, half of it at a tie, none below
+            const float pass = mu > 1e-3f ? 1.f : (mu == 1e-3f ? 0.5f : 0.f);
+            go[(long)(2 * b) * HW + i] = g * (-2.f * dd / vy + gvn * e * pass);
+            go[(long)(2 * b + 1) * HW + i] = g * dvy * 2.f * a;
+            acc += gvn * m;
+        } else {
+            const float s = e, vn = s * s;
+            const float vy = a * a + vn, dd = xv - mu;
+            const float dvy = 1.f / vy - dd * dd / (vy * vy);
+            go[(long)(2 * b) * HW + i] = g * (-2.f * dd / vy);
+            go[(long)(2 * b + 1) * HW + i] = g * dvy * 2.f * a;
+            acc += dvy * 2.f * s - 0.05f;
+        }
     }
     const float tot = block_sum(acc, red);
     if (threadIdx.x == 0) partial[b * gridDim.x + blockIdx.x] = tot * g;
@@ -665,16 +693,22 @@ int sprk_pu_loss(const float *p, const float *y, const float *log_binom, int B, 
 size_t sprk_ssdn_ws_bytes(int B, int HW) { return (size_t)B * ssdn_nblk(HW) * sizeof(float); }
 
 int sprk_ssdn_fwd(const float *x, const float *out_stats, const float *noise_std, float *loss, float *pme,
-                  float *model_std, int B, int HW, void *ws, size_t ws_bytes, void *stream) {
+                  float *model_std, float *noise_std_map, int style, int B, int HW, void *ws, size_t ws_bytes,
+                  void *stream) {
     SPRK_REQUIRE(x && out_stats && noise_std && loss && B > 0 && HW > 0, "ssdn_fwd: bad arguments");
+    SPRK_REQUIRE(style == SPRK_NOISE_GAUSSIAN || style == SPRK_NOISE_POISSON, "ssdn_fwd: unknown noise style");
     const int nblk = ssdn_nblk(HW);
     if (!ws || ws_bytes < (size_t)B * nblk * sizeof(float)) {
         sprk::set_error("ssdn_fwd: workspace too small");
         return SPRK_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ssdn_fwd_kernel, dim3(nblk, B), dim3(kSsdnBlk), 0, s, x, out_stats, noise_std, (float *)ws, pme,
-                       model_std, HW);
+    if (style == SPRK_NOISE_POISSON)
+        hipLaunchKernelGGL(ssdn_fwd_kernel<true>, dim3(nblk, B), dim3(kSsdnBlk), 0, s, x, out_stats, noise_std, (float *)ws,
+                           pme, model_std, noise_std_map, HW);
+    else
+        hipLaunchKernelGGL(ssdn_fwd_kernel<false>, dim3(nblk, B), dim3(kSsdnBlk), 0, s, x, out_stats, noise_std, (float *)ws,
+                           pme, model_std, noise_std_map, HW);
     if (int rc = sprk::check_launch("ssdn_fwd")) return rc;
     hipLaunchKernelGGL(ssdn_finish_kernel, dim3(sprk::cdiv(B, 64)), dim3(64), 0, s, (const float *)ws, loss, B, nblk,
                        1.0f / (float)HW);
@@ -682,17 +716,23 @@ int sprk_ssdn_fwd(const float *x, const float *out_stats, const float *noise_std
 }
 
 int sprk_ssdn_bwd(const float *gloss, const float *x, const float *out_stats, const float *noise_std,
-                  float *g_out_stats, float *g_noise_std, int B, int HW, void *ws, size_t ws_bytes, void *stream) {
+                  float *g_out_stats, float *g_noise_std, int style, int B, int HW, void *ws, size_t ws_bytes,
+                  void *stream) {
     SPRK_REQUIRE(gloss && x && out_stats && noise_std && g_out_stats && g_noise_std && B > 0 && HW > 0,
                  "ssdn_bwd: bad arguments");
+    SPRK_REQUIRE(style == SPRK_NOISE_GAUSSIAN || style == SPRK_NOISE_POISSON, "ssdn_bwd: unknown noise style");
     const int nblk = ssdn_nblk(HW);
     if (!ws || ws_bytes < (size_t)B * nblk * sizeof(float)) {
         sprk::set_error("ssdn_bwd: workspace too small");
         return SPRK_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ssdn_bwd_kernel, dim3(nblk, B), dim3(kSsdnBlk), 0, s, gloss, x, out_stats, noise_std,
-                       g_out_stats, (float *)ws, HW);
+    if (style == SPRK_NOISE_POISSON)
+        hipLaunchKernelGGL(ssdn_bwd_kernel<true>, dim3(nblk, B), dim3(kSsdnBlk), 0, s, gloss, x, out_stats, noise_std,
+                           g_out_stats, (float *)ws, HW);
+    else
+        hipLaunchKernelGGL(ssdn_bwd_kernel<false>, dim3(nblk, B), dim3(kSsdnBlk), 0, s, gloss, x, out_stats, noise_std,
+                           g_out_stats, (float *)ws, HW);
     if (int rc = sprk::check_launch("ssdn_bwd")) return rc;
     hipLaunchKernelGGL(ssdn_finish_kernel, dim3(sprk::cdiv(B, 64)), dim3(64), 0, s, (const float *)ws, g_noise_std, B,
                        nblk, 1.0f);

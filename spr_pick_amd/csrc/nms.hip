@@ -408,7 +408,7 @@ int sprk_nms2d(const float *scores, int H, int W, int r, float threshold, float 
             return SPRK_ELAUNCH;
         }
     }
-    static const int nms_diag = getenv("SPRK_NMS_DIAG") ? atoi(getenv("SPRK_NMS_DIAG")) : 0;   // timing experiments only
+    static const int nms_diag = sprk::diag_env("SPRK_NMS_DIAG");   // timing experiments only
     NmsArgs a{scores, st, tile_und, picks, counters, L.cap, H, W, r, L.tilesX, nms_diag};
     const bool lds = r <= kMaxLdsR;
     const int side = TS + 2 * r;

@@ -564,7 +564,7 @@ static int wgrad16_run_1x1(const Wgrad16Call &c, const Plan1 &p, const float *x,
     a.x = x; a.gy = gy; a.partial = (float *)ws;
     a.N = c.N; a.Cin = c.C1; a.Cout = c.Cout; a.HW = c.H * c.W;
     a.regPerImg = p.regPerImg; a.nRegions = p.nRegions; a.perPart = p.perPart;
-    static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
+    static const int diag = sprk::diag_env("SPRK_C16_DIAG");
     a.diag = diag;
     dim3 grid(p.parts, p.coBlocks, p.ciBlocks);
     auto go = [&](auto kernel) {
@@ -610,7 +610,7 @@ int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const flo
     a.x = x; a.x2 = x2; a.gy = gy; a.partial = (float *)ws;
     a.N = c.N; a.C1 = c.C1; a.C2 = c.C2; a.H = c.H; a.W = c.W; a.Cout = c.Cout; a.padT = c.padT; a.padL = c.padL;
     a.regX = p.regX; a.regY = p.regY; a.seg = p.seg; a.segLen = p.segLen; a.nUnits = p.nUnits; a.xcs = p.xcs; a.tail = p.tail;
-    static const int diag = getenv("SPRK_C16_DIAG") ? atoi(getenv("SPRK_C16_DIAG")) : 0;
+    static const int diag = sprk::diag_env("SPRK_C16_DIAG");
     a.diag = diag;
     a.xcd = xcd_on();
     const int dt = c.dtype & SPRK_DT_MASK;

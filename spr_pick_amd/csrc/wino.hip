@@ -843,7 +843,7 @@ int wino_conv(const WinoArgs &w, hipStream_t s) {
     a.mask = w.up2 ? nullptr : w.mask;
     a.mact = w.mask_act;
     a.xcd = xcd_on();
-    static const int diag = getenv("SPRK_WINO_DIAG") ? atoi(getenv("SPRK_WINO_DIAG")) : 0;   // timing experiments only
+    static const int diag = sprk::diag_env("SPRK_WINO_DIAG");   // timing experiments only
     a.diag = diag;
     const int sq = wino_square(w.H, w.W);
     a.tilesX = w.W / (sq ? Geo<1>::TC : Geo<0>::TC); a.tilesY = w.H / (sq ? Geo<1>::TR : Geo<0>::TR);

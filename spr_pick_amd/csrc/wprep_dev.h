@@ -155,8 +155,9 @@ int wprep_site(const sprk_wprep_item &it, hipStream_t s);
 int wprep_launch(const sprk_wprep_item *items, int n, hipStream_t s);
 // RAII: the mode of the entry point running on this thread
 struct WprepScope {
-    WprepScope(sprk_wprep_item *describe, bool skip);
+    WprepScope(sprk_wprep_item *describe, int dtype);      // dtype: the call's sprk_conv_geom.dtype (SPRK_DT_WPREP bits)
     ~WprepScope();
+    int verify(int rc) const;                               // rc of the call -> rc, or SPRK_EINVAL on a kind mismatch
 };
 bool wprep_describing();
 

@@ -237,14 +237,20 @@ class Denoiser(nn.Module):
         return net_out, logits, noise_std
 
     def _check_style(self):
+        """-> ops.NOISE_* of the configured likelihood (denoiser_v2.py:405-424): gaussian, or the signal-dependent
+        poisson approximation with an unknown parameter."""
         style = self.cfg[ConfigValue.NOISE_STYLE]
-        if style is None or not style.startswith("gauss"):
-            raise NotImplementedError("only the gaussian likelihood branch (--noise_style gauss*) is on the hot path")
+        if style is not None and style.startswith("gauss"):
+            return ops.NOISE_GAUSSIAN
+        if style is not None and style.startswith("poisson"):
+            return ops.NOISE_POISSON
+        raise NotImplementedError("noise style %r: the reference's likelihood covers gauss* and poisson* only "
+                                  "(denoiser_v2.py:405-424)" % (style,))
 
     def _new_pipeline(self, data, alpha, tau, train, eps=None, eps_flip=None, flip_p=None, tile=None, halo=512, **kwargs):
         if not len(data) > 2:
             return None  # as the reference: the joint pipeline needs the full batch list (denoiser_v2.py:261)
-        self._check_style()
+        style = self._check_style()
         inp, target = data[DetectionDataset.INPUT], data[DetectionDataset.TARGET]
         hm = data[DetectionDataset.HM]
         metadata = data[DetectionDataset.METADATA]
@@ -271,7 +277,7 @@ class Denoiser(nn.Module):
         mu_x = net_out[:, 0:1]
         if not (tile and not train):
             noise_std = self._noise_std(inp)
-        loss_out, pme_out, net_std_out = ops.ssdn_nll_pme(inp, net_out, noise_std)
+        loss_out, pme_out, net_std_out, ns_map = ops.ssdn_nll_pme(inp, net_out, noise_std, style)
         if train:
             consis_loss = torch.nn.functional.mse_loss(hm_p, hm_p_f)
             final_loss = alpha * loss_out + (1 - alpha) * pred_loss + 0.1 * consis_loss
@@ -286,14 +292,14 @@ class Denoiser(nn.Module):
             PipelineOutput.IMG_DENOISED: pme_out,
             PipelineOutput.DETECT_LOSS: pred_loss,
             PipelineOutput.DENOISE_LOSS: loss_out,
-            PipelineOutput.NOISE_STD_DEV: noise_std[:, 0],
+            PipelineOutput.NOISE_STD_DEV: ns_map if style == ops.NOISE_POISSON else noise_std[:, 0],
             PipelineOutput.MODEL_STD_DEV: net_std_out,
             PipelineOutput.DETECT: hm_p,
             PipelineOutput.GT: gt,
         }
 
     def _ssdn_pipeline(self, data, **kwargs):
-        self._check_style()
+        style = self._check_style()
         inp, target = data[DetectionDataset.INPUT], data[DetectionDataset.TARGET]
         inp = inp.to(self.device, dtype=torch.float32)
         if torch.is_tensor(target):
@@ -302,14 +308,14 @@ class Denoiser(nn.Module):
         res = self.models[Denoiser.MODEL].denoise_branch(inp)
         net_out = res[0] if isinstance(res, tuple) else res
         noise_std = self._noise_std(inp)
-        loss_out, pme_out, net_std_out = ops.ssdn_nll_pme(inp, net_out, noise_std)
+        loss_out, pme_out, net_std_out, ns_map = ops.ssdn_nll_pme(inp, net_out, noise_std, style)
         return {
             PipelineOutput.INPUTS: data,
             PipelineOutput.IMG_MU: net_out[:, 0:1],
             PipelineOutput.TARGET: target,
             PipelineOutput.IMG_DENOISED: pme_out,
             PipelineOutput.LOSS: loss_out,
-            PipelineOutput.NOISE_STD_DEV: noise_std[:, 0],
+            PipelineOutput.NOISE_STD_DEV: ns_map if style == ops.NOISE_POISSON else noise_std[:, 0],
             PipelineOutput.MODEL_STD_DEV: net_std_out,
         }
 

@@ -257,6 +257,19 @@ def set_lr(optimizer, lr):
             group["lr"] = lr
 
 
+_CAPTURE_MARKERS = ("capture", "captur", "hipErrorStreamCapture", "cudaErrorStreamCapture", "operation not permitted when stream is")
+
+
+def _capture_specific(e):
+    """Is this exception a HIP-graph CAPTURE failure (unsupported operation under capture, invalidated or unjoined
+    capture) — the only kind a stepper may answer by going eager?  SprkError (a kernel wrapper refusing its arguments)
+    and every other RuntimeError are genuine errors."""
+    if isinstance(e, _lib.SprkError):
+        return False
+    msg = str(e)
+    return any(m in msg for m in _CAPTURE_MARKERS)
+
+
 class _NoPrep:
     """SPRK_WPREP=0: every convolution call transforms its own weights (A/B measurements)."""
     launches = 0
@@ -318,6 +331,7 @@ class GraphedTrainStep:
         self._warm = eager_warmup
         self._compacted = False
         self.kernels_per_step = None
+        self._recheck = False
 
     # ---- one pass, eager (also what gets captured) ---------------------------------------------------
     def _pass(self, flip_p):
@@ -360,6 +374,9 @@ class GraphedTrainStep:
                 self.grads.compact()          # this pass's gradients move to the new layout with their parameters
                 self._compacted = True
                 self.grads.check_adopted()
+            elif self._recheck:               # first eager pass after a failed capture
+                self.grads.check_adopted()
+                self._recheck = False
         cur.wait_stream(self._side)
         return o
 
@@ -419,16 +436,24 @@ class GraphedTrainStep:
         try:
             self._capture(axis_key, flip_p)
             return True
-        except (RuntimeError, _lib.SprkError) as e:
+        except RuntimeError as e:
             torch_ops.drop_pending(self.dev)
             ops.set_grad_destinations(None)
-            torch.cuda.synchronize(self.dev)
+            if not _capture_specific(e):
+                raise          # a launch failure / bad argument / device error is an error, not a performance fallback
             self.use_graph = False
             self._graphs.clear()
             self.fallback_reason = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
             import logging
             logging.getLogger(__name__).warning("HIP-graph capture of the training step failed (%s); continuing with "
                                                 "eager launches", self.fallback_reason)
+            try:
+                torch.cuda.synchronize(self.dev)
+            except RuntimeError as e2:           # the failed capture left the device in an error state: that IS fatal
+                raise RuntimeError("device error after a failed HIP-graph capture: %s" % e2) from e
+            # the half-captured pass may have handed out gradient slices and left partial sums: start the eager path clean
+            self.grads.begin_step()
+            self._recheck = True
             return False
 
     def __call__(self, inp, target, flip_p=None, eager=False, eps=None, eps_flip=None):

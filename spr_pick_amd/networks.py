@@ -54,7 +54,8 @@ class Conv2d(nn.Module):
         self.kernel_size = (kernel_size, kernel_size)
         self.stride, self.padding, self.dilation = stride, padding, dilation
         self.act = act
-        self.mfma_dtype = 0      # _lib.DT_*: operand precision of this layer's MFMA kernels (set_conv_dtype)
+        self.mfma_dtype = 0      # _lib.DT_*: operand precision of this layer's MFMA kernels (set_conv_dtype) ...
+        self.mfma_dtype_nograd = 0   # ... while autograd records (training) / under no_grad (inference)
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
@@ -76,7 +77,7 @@ class Conv2d(nn.Module):
         x_act / premasked: activation backward fused into the neighbouring operators (ops.conv2d)."""
         # inference (no autograd): the kernel choice is pinned to the layer's structure (_lib.DT_PIN), so that a window
         # of a micrograph gets the very arithmetic the whole micrograph gets (Denoiser._tiled_networks)
-        dtype = self.mfma_dtype if torch.is_grad_enabled() else (self.mfma_dtype | DT_PIN)
+        dtype = self.mfma_dtype if torch.is_grad_enabled() else (self.mfma_dtype_nograd | DT_PIN)
         return ops.conv2d(x, self.weight, self.bias, x2=skip, up1=up, stride=self.stride, dil=self.dilation,
                           pad=self._pad(), act=self.act, up_out=up_out, dtype=dtype, x_act=x_act, premasked=premasked)
 
@@ -208,18 +209,27 @@ class _UNetBase(nn.Module):
 
 
 def set_conv_dtype(module, dtype):
-    """Operand precision ("f32" | "bf16" | "f16") of the convolutions of every U-Net under ``module`` — the layers
-    that carry 99.6 % of the FLOPs.  The detector (BatchNorm statistics over 64-patch batches,
-    0.4 % of the FLOPs) and each U-Net's final 1x1 output convolution (it produces mu and the variance factor the
-    likelihood is evaluated on) always run in fp32.  Returns the number of layers switched."""
-    from ._lib import DTYPES
-    code = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+    """Operand precision ("f32" | "bf16" | "f16" | "mixed16") of the convolutions of every U-Net under ``module`` — the
+    layers that carry 99.6 % of the FLOPs.  The detector (BatchNorm statistics over 64-patch
+    batches, 0.4 % of the FLOPs) and each U-Net's final 1x1 output convolution (it produces mu and the variance factor
+    the likelihood is evaluated on) always run in fp32.  Returns the number of layers switched.
+
+    "mixed16" is the 16-bit mode of BASELINE configs[4]: bf16 operands while autograd records (forward, backward-data,
+    backward-weight of a training step), fp16 operands under no_grad (inference).  Same MFMA rate; fp16 has 8x the
+    resolution, which the picks want (agreement with fp32 picks 0.99), but its range loses the U-Nets'
+    gradients: a run trained with fp16 operands end to end leaves the sigma-net at its floor and reaches AP 0.65 where
+    fp32 and bf16 reach 0.93 (profiles/r04_full_pipeline.json)."""
+    from ._lib import DT_BF16, DT_F16, DTYPES
+    if dtype == "mixed16":
+        code, code_ng = DT_BF16, DT_F16
+    else:
+        code = code_ng = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
     n = 0
     for net in module.modules():
         if isinstance(net, _UNetBase):
             for name, m in net.named_modules():
                 if isinstance(m, Conv2d) and not name.startswith("output_conv"):
-                    m.mfma_dtype = code
+                    m.mfma_dtype, m.mfma_dtype_nograd = code, code_ng
                     n += 1
     return n
 

@@ -93,10 +93,14 @@ class WeightPrep:
     first node of the captured graphs)."""
 
     def __init__(self):
-        self.entries = {}        # key -> (workspace tensor, the weight tensor it was made from)
+        self.clear()
+        self.launches = 0
+
+    def clear(self):
+        """Forget every kept workspace (the model or the stepper is being rebuilt)."""
+        self.entries = {}        # key -> (workspace tensor, the weight tensor it was made from, kind of the transform)
         self.items = []          # _lib.WprepItem of every entry with a transform
         self._table = None
-        self.launches = 0
 
     def __enter__(self):
         global _WPREP
@@ -111,17 +115,24 @@ class WeightPrep:
     def begin_step(self, like):
         if not self.items:
             return
+        for key, (_, w, _) in self.entries.items():
+            if w.data_ptr() != key[1]:
+                raise _lib.SprkError("WeightPrep: the storage of a %s weight was replaced after its transform was recorded; "
+                                     "call clear() (or build a new stepper) after swapping parameters" % (tuple(w.shape),))
         if self._table is None or len(self._table) != len(self.items):
             self._table = (_lib.WprepItem * len(self.items))(*self.items)
         check(_lib.lib().sprk_prepare_weights(self._table, len(self.items), _stream(like)), "sprk_prepare_weights")
         self.launches += 1
 
     def lookup(self, key):
+        """-> (workspace, dtype bits of a prepared call: SPRK_DT_WPREP + the kind the workspace holds) or (None, 0)"""
         e = self.entries.get(key)
-        return e[0] if e is not None else None
+        if e is None:
+            return None, 0
+        return e[0], _lib.DT_WPREP | ((e[2] & 7) << 12)
 
     def record(self, key, w, ws, item):
-        self.entries[key] = (ws, w)
+        self.entries[key] = (ws, w, int(item.kind))
         if item.kind:
             self.items.append(item)
 
@@ -135,10 +146,10 @@ def _prep_fwd(w, g, ep_key, ep):
     if _WPREP is None:
         return g, None
     key = ("f", w.data_ptr(), tuple(geom_list(g)), ep_key)
-    ws = _WPREP.lookup(key)
+    ws, bits = _WPREP.lookup(key)
     if ws is not None:
         gp = ConvGeom(*geom_list(g))
-        gp.dtype = g.dtype | _lib.DT_WPREP
+        gp.dtype = g.dtype | bits
         return gp, ws
     L = _lib.lib()
     ws = _ws(L.sprk_conv2d_fwd_ws_bytes(ctypes.byref(g)), w)
@@ -153,10 +164,10 @@ def _prep_bwd(w, g):
     if _WPREP is None:
         return g, None
     key = ("b", w.data_ptr(), tuple(geom_list(g)))
-    ws = _WPREP.lookup(key)
+    ws, bits = _WPREP.lookup(key)
     if ws is not None:
         gp = ConvGeom(*geom_list(g))
-        gp.dtype = g.dtype | _lib.DT_WPREP
+        gp.dtype = g.dtype | bits
         return gp, ws
     L = _lib.lib()
     ws = _ws(L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(g)), w)
@@ -471,29 +482,35 @@ def pu_loss(p, y, log_binom, slack=4.0):
     return _PuLossFn.apply(p, y, log_binom, slack)
 
 
+NOISE_GAUSSIAN, NOISE_POISSON = 0, 1      # SPRK_NOISE_* (include/sprk.h)
+
+
 class _SsdnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, out_stats, noise_std):
+    def forward(ctx, x, out_stats, noise_std, style):
         x = x.contiguous()
         out_stats = out_stats.contiguous()
         ns = noise_std.reshape(-1).contiguous()
         _need_gpu(x, out_stats, ns)
-        loss, pme, mstd = _S.ssdn_fwd(x, out_stats, ns)
+        loss, pme, mstd, nsmap = _S.ssdn_fwd(x, out_stats, ns, style)
         ctx.save_for_backward(x, out_stats, ns)
         ctx.ns_shape = noise_std.shape
-        ctx.mark_non_differentiable(pme, mstd)
-        return loss, pme, mstd
+        ctx.style = style
+        ctx.mark_non_differentiable(pme, mstd, nsmap)
+        return loss, pme, mstd, nsmap
 
     @staticmethod
-    def backward(ctx, gloss, _gpme, _gmstd):
+    def backward(ctx, gloss, _gpme, _gmstd, _gmap):
         x, out_stats, ns = ctx.saved_tensors
-        go, gns = _S.ssdn_bwd(gloss.reshape(-1).contiguous(), x, out_stats, ns)
-        return None, go, gns.reshape(ctx.ns_shape)
+        go, gns = _S.ssdn_bwd(gloss.reshape(-1).contiguous(), x, out_stats, ns, ctx.style)
+        return None, go, gns.reshape(ctx.ns_shape), None
 
 
-def ssdn_nll_pme(x, out_stats, noise_std):
-    """(loss [B,1] = per-image mean NLL, pme [B,1,H,W], model_std [1,B,H,W])."""
-    return _SsdnFn.apply(x, out_stats, noise_std)
+def ssdn_nll_pme(x, out_stats, noise_std, style=NOISE_GAUSSIAN):
+    """(loss [B,1] = per-image mean NLL, pme [B,1,H,W], model_std [1,B,H,W], noise_std_map).
+    noise_std: the remapped estimate [B,1,1,1]; gaussian: it is the noise standard deviation and noise_std_map is
+    empty; poisson (denoiser_v2.py:412-424): std = sqrt(max(mu, 1e-3) * estimate) per pixel -> noise_std_map [B,H,W]."""
+    return _SsdnFn.apply(x, out_stats, noise_std, int(style))
 
 
 def head1x1_eligible(f, c1, c2, c3):
@@ -503,7 +520,7 @@ def head1x1_eligible(f, c1, c2, c3):
     return (not torch.is_grad_enabled() and f.is_cuda and f.dtype == torch.float32 and (K0, N1) in ((384, 384), (96, 96))
             and tuple(c2.weight.shape[:2]) == (96, N1) and c3.weight.shape[1] == 96 and c3.weight.shape[0] in (1, 2)
             and c1.kernel_size == (1, 1) and c1.act == ACT_LEAKY and c2.act == ACT_LEAKY and c3.act == ACT_NONE
-            and all(c.bias is not None and (c.mfma_dtype & 0xff) == 0 for c in (c1, c2, c3))
+            and all(c.bias is not None and (c.mfma_dtype_nograd & 0xff) == 0 for c in (c1, c2, c3))
             and (f.shape[2] * f.shape[3]) % 128 == 0 and f.shape[2] * f.shape[3] < (1 << 25) and f.shape[1] == K0)
 
 
@@ -522,7 +539,7 @@ def head1x1_unrot_eligible(d, c1, c2, c3):
     return (not torch.is_grad_enabled() and d.is_cuda and d.dtype == torch.float32 and (K0, N1) == (384, 384)
             and tuple(c2.weight.shape[:2]) == (96, 384) and c3.weight.shape[1] == 96 and c3.weight.shape[0] in (1, 2)
             and c1.kernel_size == (1, 1) and c1.act == ACT_LEAKY and c2.act == ACT_LEAKY and c3.act == ACT_NONE
-            and all(c.bias is not None and (c.mfma_dtype & 0xff) == 0 for c in (c1, c2, c3))
+            and all(c.bias is not None and (c.mfma_dtype_nograd & 0xff) == 0 for c in (c1, c2, c3))
             and d.shape[2] * d.shape[3] < (1 << 25))
 
 

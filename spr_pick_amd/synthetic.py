@@ -2,7 +2,13 @@
 + Gaussian blobs, min-max normalised and quantised to uint8 like the reference's loader
 (utils/loader.py:57-59); labelled centres carry CenterNet-style gaussian targets, everything
 else is unlabelled (-1), sampled with 10 % positives like StratifiedCoordinateSampler
-(datasets/sampler.py).  Used by bench.py and the tests; data only, no kernels."""
+(datasets/sampler.py).  ``write_dataset`` puts such a set on disk in the formats the `joint` CLI reads
+(MRC micrographs + the image / coordinate tables of README.md:29-47), with the labelled subset the README
+describes (part of the particles inside a ~300x300 sub-region) and, beside it, the table of ALL planted
+centres that recall / precision of the picks are measured against.
+Used by bench.py, full_pipeline.py and the tests; data only, no kernels."""
+import os
+
 import numpy as np
 import torch
 
@@ -44,4 +50,32 @@ def patch_batches(n_batches, batch, micrographs, patch=64, seed=0, device="cuda"
                 y, x = (int(v) for v in rng.integers(73, size - 140, size=2))
             inp[b, 0] = mics[m][y - half:y + half, x - half:x + half]
         out.append((inp.to(device), tgt))
+    return out
+
+
+def write_dataset(root, n, size=1024, seed=1234, blobs=None, prefix="mic"):
+    """n synthetic micrographs as float32 MRC files under `root` + ``images.txt`` (image_name, path),
+    ``labels.txt`` (image_name, x_coord, y_coord: the labelled subset: 60 % of the centres inside the
+    300x300 corner window) and ``truth.txt`` (same columns, every planted centre).
+    x_coord = column, y_coord = row of the stored array.  -> dict of the three paths + counts."""
+    from . import micrograph_io
+    os.makedirs(root, exist_ok=True)
+    images, labels, truth = ["image_name\tpath"], ["image_name\tx_coord\ty_coord"], ["image_name\tx_coord\ty_coord"]
+    n_lab = n_all = 0
+    for k in range(n):
+        q, centres, labelled = micrograph(k, size=size, blobs=blobs, seed=seed)
+        name = "%s%04d" % (prefix, k)
+        path = os.path.join(root, name + ".mrc")
+        with open(path, "wb") as f:
+            micrograph_io.write_mrc(f, q.astype(np.float32))
+        images.append("%s\t%s" % (name, path))
+        labels += ["%s\t%d\t%d" % (name, cx, cy) for cy, cx in labelled]
+        truth += ["%s\t%d\t%d" % (name, cx, cy) for cy, cx in centres]
+        n_lab += len(labelled)
+        n_all += len(centres)
+    out = {"images": os.path.join(root, "images.txt"), "labels": os.path.join(root, "labels.txt"),
+           "truth": os.path.join(root, "truth.txt"), "n": n, "size": size, "labelled": n_lab, "planted": n_all}
+    for key, lines in (("images", images), ("labels", labels), ("truth", truth)):
+        with open(out[key], "w") as f:
+            f.write("\n".join(lines) + "\n")
     return out

@@ -299,38 +299,42 @@ _register("pu_loss", "(Tensor p, Tensor y, Tensor log_binom, float slack) -> (Te
           lambda p, y, t, slack: (p.new_empty((1,)), p.new_empty((p.numel(),))))
 
 
-def _ssdn_fwd(x, out_stats, noise_std):
+def _ssdn_fwd(x, out_stats, noise_std, style):
+    """-> (loss [B,1], pme [B,1,H,W], model_std [1,B,H,W], noise_std_map [B,H,W] (poisson) or empty (gaussian))"""
     L = _lib.lib()
     B, _, H, W = out_stats.shape
     loss, pme, mstd = _f32(x, (B, 1)), _f32(x, (B, 1, H, W)), _f32(x, (1, B, H, W))
+    nsmap = _f32(x, (B, H, W)) if style == 1 else _f32(x, (0,))
     nb = L.sprk_ssdn_ws_bytes(B, H * W)
     ws = _ws(nb, x)
-    check(L.sprk_ssdn_fwd(_p(x), _p(out_stats), _p(noise_std), _p(loss), _p(pme), _p(mstd), B, H * W, _p(ws), nb,
-                          _stream(x)), "sprk_ssdn_fwd")
-    return loss, pme, mstd
+    check(L.sprk_ssdn_fwd(_p(x), _p(out_stats), _p(noise_std), _p(loss), _p(pme), _p(mstd), _p(nsmap) if style == 1 else None,
+                          int(style), B, H * W, _p(ws), nb, _stream(x)), "sprk_ssdn_fwd")
+    return loss, pme, mstd, nsmap
 
 
-def _ssdn_fwd_fake(x, out_stats, noise_std):
+def _ssdn_fwd_fake(x, out_stats, noise_std, style):
     B, _, H, W = out_stats.shape
-    return x.new_empty((B, 1)), x.new_empty((B, 1, H, W)), x.new_empty((1, B, H, W))
+    return (x.new_empty((B, 1)), x.new_empty((B, 1, H, W)), x.new_empty((1, B, H, W)),
+            x.new_empty((B, H, W) if style == 1 else (0,)))
 
 
-_register("ssdn_fwd", "(Tensor x, Tensor out_stats, Tensor noise_std) -> (Tensor, Tensor, Tensor)", _ssdn_fwd, _ssdn_fwd_fake)
+_register("ssdn_fwd", "(Tensor x, Tensor out_stats, Tensor noise_std, int style) -> (Tensor, Tensor, Tensor, Tensor)", _ssdn_fwd,
+          _ssdn_fwd_fake)
 
 
-def _ssdn_bwd(gloss, x, out_stats, noise_std):
+def _ssdn_bwd(gloss, x, out_stats, noise_std, style):
     L = _lib.lib()
     B, _, H, W = out_stats.shape
     go, gns = torch.empty_like(out_stats), _f32(x, (B,))
     nb = L.sprk_ssdn_ws_bytes(B, H * W)
     ws = _ws(nb, x)
-    check(L.sprk_ssdn_bwd(_p(gloss), _p(x), _p(out_stats), _p(noise_std), _p(go), _p(gns), B, H * W, _p(ws), nb,
+    check(L.sprk_ssdn_bwd(_p(gloss), _p(x), _p(out_stats), _p(noise_std), _p(go), _p(gns), int(style), B, H * W, _p(ws), nb,
                           _stream(x)), "sprk_ssdn_bwd")
     return go, gns
 
 
-_register("ssdn_bwd", "(Tensor gloss, Tensor x, Tensor out_stats, Tensor noise_std) -> (Tensor, Tensor)", _ssdn_bwd,
-          lambda gl, x, o, ns: (torch.empty_like(o), x.new_empty((o.shape[0],))))
+_register("ssdn_bwd", "(Tensor gloss, Tensor x, Tensor out_stats, Tensor noise_std, int style) -> (Tensor, Tensor)", _ssdn_bwd,
+          lambda gl, x, o, ns, style: (torch.empty_like(o), x.new_empty((o.shape[0],))))
 
 
 # ---- BatchNorm -----------------------------------------------------------------------------------------------------------

@@ -24,13 +24,14 @@ import logging
 import math
 import os
 import re
+import time
 from collections import defaultdict
 
 import numpy as np
 import torch
 
 from . import cfg as cfg_mod
-from . import checkpoint, distributed, feed as feed_mod, graph_step, picks
+from . import checkpoint, distributed, feed as feed_mod, graph_step, outputs as outputs_mod, picks
 from .algorithms import nms_device
 from .datasets import DetectionDataset
 from .denoiser import Denoiser
@@ -40,6 +41,7 @@ from .utils import Metric, MetricDict, TrackedTime, compute_ramped_lrate, second
 logger = logging.getLogger("joint.train")
 BASE_LR = 1e-4
 NMS_THRESHOLD = 0.02
+EVAL_NOISE_SEED = 7_000_000      # + micrograph index = seed of that micrograph's evaluation noise stream
 
 
 def setup_logging(run_dir_path, filename="log.txt"):
@@ -53,14 +55,7 @@ def setup_logging(run_dir_path, filename="log.txt"):
         root.addHandler(h)
 
 
-def tensor_to_png(img, path):
-    """save_tensor_image (utils/data.py:71-93,143-147): min-max normalise the [1,a,b] tensor, swap the
-    two image axes back to the file's orientation, quantise with uint8(x*255)."""
-    from PIL import Image
-    x = img.detach().to(torch.float32).cpu().numpy()
-    lo, hi = float(x.min()), float(x.max())
-    x = (x - lo) / (hi - lo) if hi > lo else np.zeros_like(x)
-    Image.fromarray(np.uint8(x[0].T * 255), mode="L").save(path)
+tensor_to_png = outputs_mod.tensor_to_png      # save_tensor_image (utils/data.py:71-93,143-147), see outputs.py
 
 
 class DenoiserTrainer:
@@ -86,6 +81,8 @@ class DenoiserTrainer:
         self._metrics_file = None
         self._eval_modes_logged = set()
         self.trainfeed, self.testfeed = None, None
+        self.writer = outputs_mod.OutputWriter()       # PNG / score files leave the loop through a thread pool
+        self.timing = {}                                # wall clocks of the phases (seconds), for reports
 
     # ---- model / optimiser ---------------------------------------------------------------------
     @property
@@ -95,6 +92,12 @@ class DenoiserTrainer:
     @denoiser.setter
     def denoiser(self, denoiser):
         self._denoiser = denoiser
+        # operand precision of the U-Nets' MFMA convolutions: not a flag of the reference's CLI, so the drop-in
+        # command line stays as it is and the choice travels in the environment (f32 | bf16 | f16; BASELINE configs[4])
+        dt = os.environ.get("SPRK_CONV_DTYPE", "f32")
+        if dt != "f32":
+            n = denoiser.set_conv_dtype(dt)
+            logger.info("MFMA operand precision %s requested for %d convolution layers (SPRK_CONV_DTYPE)", dt, n)
         self.init_optimiser()
 
     def init_optimiser(self):
@@ -150,6 +153,7 @@ class DenoiserTrainer:
         if self.denoiser is None:
             self.new_target()
         denoiser = self.denoiser
+        t_setup = time.perf_counter()
         os.makedirs(self.run_dir_path, exist_ok=True)
         if self.rank == 0:
             setup_logging(self.run_dir_path)
@@ -169,8 +173,11 @@ class DenoiserTrainer:
         history = self.state[StateValue.HISTORY]
         train_history = history[HistoryValue.TRAIN]
         joint = self.mode == "joint"
+        self.timing["setup_s"] = time.perf_counter() - t_setup
+        t_loop, it_loop, t_other = time.perf_counter(), self.state[StateValue.ITERATION], 0.0
         while True:
             iteration = self.state[StateValue.ITERATION]
+            t_side = time.perf_counter()
             if iteration % c[ConfigValue.EVAL_INTERVAL] == 0 and self.testfeed is not None:
                 torch.cuda.empty_cache()
                 self._evaluate(self.testfeed, output_callback=self.validation_output_callback(0))
@@ -186,6 +193,8 @@ class DenoiserTrainer:
                 self.reset_metrics()
             if iteration % c[ConfigValue.SNAPSHOT_INTERVAL] == 0:
                 self.snapshot()
+            if iteration % c[ConfigValue.EVAL_INTERVAL] == 0 or iteration % c[ConfigValue.SNAPSHOT_INTERVAL] == 0:
+                t_other += time.perf_counter() - t_side       # validation passes and checkpoints: not the step loop
             if iteration >= c[ConfigValue.ITERATIONS]:
                 break
 
@@ -217,7 +226,19 @@ class DenoiserTrainer:
             self.state[StateValue.ITERATION] += image_count
 
         st = self._stepper
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self.timing["loop_s"] = time.perf_counter() - t_loop - t_other
+        self.timing["loop_images"] = self.state[StateValue.ITERATION] - it_loop
+        self.timing["validation_and_checkpoint_s"] = t_other
         if st is not None:
+            self.timing["execution"] = ("eager launches (capture failed: %s)" % st.fallback_reason if st.fallback_reason else
+                                        ("HIP-graph replay, %d kernels per step" % (st.kernels_per_step or 0)
+                                         if st.use_graph else "eager launches"))
+            self.timing["graph_fallback"] = st.fallback_reason
+            logger.info("training loop: %d images in %.1f s = %.1f patches/s (validation + checkpoints %.1f s beside it)",
+                        self.timing["loop_images"], self.timing["loop_s"],
+                        self.timing["loop_images"] / max(self.timing["loop_s"], 1e-9), t_other)
             logger.info("step execution: %s; gradient collectives: %d%s",
                         "eager launches (capture failed: %s)" % st.fallback_reason if st.fallback_reason else
                         ("HIP-graph replay (%d kernels per step)" % (st.kernels_per_step or 0) if st.use_graph else "eager launches"),
@@ -237,17 +258,38 @@ class DenoiserTrainer:
     def _evaluate(self, feed, output_callback):
         self.denoiser.eval()
         self.denoiser.fill()
+        cuda = self.device.type == "cuda"
+        t_loop = time.perf_counter()
+        spans = []
+        gen = torch.Generator(device=self.device) if cuda else None
         with torch.no_grad():
             eval_history = self.state[StateValue.HISTORY][HistoryValue.EVAL]
             for idx, data in feed:
-                image_count = data[DetectionDataset.INPUT].shape[0]
-                tile, halo = self._eval_tile(data[DetectionDataset.INPUT])
-                shape = tuple(int(v) for v in data[DetectionDataset.INPUT].shape[-2:])
+                inp = data[DetectionDataset.INPUT]
+                image_count = inp.shape[0]
+                tile, halo = self._eval_tile(inp)
+                shape = tuple(int(v) for v in inp.shape[-2:])
                 if (shape, tile) not in self._eval_modes_logged:
                     self._eval_modes_logged.add((shape, tile))
                     logger.info("evaluation of %dx%d inputs: %s", shape[0], shape[1],
                                 "whole image" if tile is None else "halo-tiled, tile %d halo %d" % (tile, halo))
-                outputs = self.denoiser.run_pipeline(data, train=False, tile=tile, halo=halo or 0)
+                eps = None
+                if cuda and self.mode == "joint":
+                    # the reparameterisation noise of micrograph k comes from a Philox stream seeded with k (SURVEY.md
+                    # §8d): the picks of a micrograph do not depend on which rank evaluates it, in which order, or on
+                    # what was drawn before — and two operand precisions can be compared on the same noise
+                    k = int(data[DetectionDataset.METADATA][DetectionDataset.Metadata.INDEXES][0])
+                    gen.manual_seed(EVAL_NOISE_SEED + k)
+                    eps = torch.randn((inp.shape[0], 1) + shape, dtype=torch.float32, device=self.device, generator=gen)
+                if cuda:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                try:
+                    outputs = self.denoiser.run_pipeline(data, train=False, tile=tile, halo=halo or 0, eps=eps)
+                except torch.OutOfMemoryError as e:
+                    raise RuntimeError("out of device memory evaluating a %dx%d input %s; set SPRK_EVAL_TILE=tile[,halo] "
+                                       "(e.g. 2048,512) to evaluate in smaller halo-tiled windows" % (
+                                           shape[0], shape[1], "whole" if tile is None else "in windows of %d" % (tile + 2 * halo))) from e
                 eval_history["n"] += image_count
                 clean = outputs[PipelineOutput.INPUTS][DetectionDataset.METADATA][DetectionDataset.Metadata.GT]
                 if len(clean) > 0:   # PSNR against the clean reference images (train.py:404-413)
@@ -255,13 +297,31 @@ class DenoiserTrainer:
                         eval_history[name] += self.calculate_psnr(outputs, key)
                 if output_callback:
                     output_callback(idx, outputs)
+                if cuda:
+                    e1.record()
+                    spans.append((e0, e1))
+        self.writer.drain()
+        if cuda:
+            torch.cuda.synchronize(self.device)
+            self.timing["eval_device_s"] = self.timing.get("eval_device_s", 0.0) + sum(a.elapsed_time(b) for a, b in spans) * 1e-3
+        self.timing["eval_loop_s"] = self.timing.get("eval_loop_s", 0.0) + time.perf_counter() - t_loop
+        self.timing["eval_micrographs"] = self.timing.get("eval_micrographs", 0) + len(spans)
         self.denoiser.unfill()
 
-    # Whole-image evaluation up to this many pixels (4096^2: 82 GB of the 288 GB of one MI355X), halo-tiled above.
-    # The choice depends on the micrograph's SIZE only — never on what else holds HBM — so the same checkpoint and
-    # micrograph always produce the same *_scores.txt; the mode is written to the log.
-    WHOLE_IMAGE_MAX_PIXELS = 4096 * 4096
+    # Whole-image evaluation while the working set (WORKING_SET_BYTES_PER_PIXEL, measured: 57 GB peak at 4096^2 + margin)
+    # fits in WHOLE_IMAGE_HBM_FRACTION of the device's TOTAL memory (288 GB on MI355X -> 4096^2 = 16.8 Mpix is whole, as
+    # BASELINE configs[2] needs), halo-tiled above.  The choice depends on the micrograph's SIZE and the device MODEL only —
+    # never on what else holds HBM at the moment — so the same checkpoint and micrograph always produce the same
+    # *_scores.txt on the same kind of GPU; the mode is written to the log.
+    WORKING_SET_BYTES_PER_PIXEL = 5000
+    WHOLE_IMAGE_HBM_FRACTION = 0.30
     EVAL_TILE, EVAL_HALO = 3072, 512     # windows of 4096^2: the whole-image kernels, 1.78x the pixels
+
+    def whole_image_max_pixels(self):
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            return 4096 * 4096
+        total = torch.cuda.get_device_properties(self.device).total_memory
+        return int(total * self.WHOLE_IMAGE_HBM_FRACTION / self.WORKING_SET_BYTES_PER_PIXEL)
 
     def _eval_tile(self, inp):
         """(tile, halo) for halo-tiled evaluation, or (None, None) for the whole-image path.  SPRK_EVAL_TILE =
@@ -272,9 +332,16 @@ class DenoiserTrainer:
             parts = [int(v) for v in env.split(",")]
             t, h = parts[0], (parts[1] if len(parts) > 1 else self.EVAL_HALO)
             return (t, h) if t > 0 and min(H, W) >= t + 2 * h else (None, None)
-        if self.mode != "joint" or H * W <= self.WHOLE_IMAGE_MAX_PIXELS or min(H, W) < self.EVAL_TILE + 2 * self.EVAL_HALO:
+        limit = self.whole_image_max_pixels()
+        if self.mode != "joint" or H * W <= limit:
             return None, None
-        return self.EVAL_TILE, self.EVAL_HALO
+        tile, halo = self.EVAL_TILE, self.EVAL_HALO
+        while tile + 2 * halo > min(H, W) and tile > 1024:       # a long, narrow image: smaller windows
+            tile -= 1024
+        if min(H, W) < tile + 2 * halo:
+            raise RuntimeError("a %dx%d input exceeds the whole-image limit of this device (%d pixels) and is too narrow for "
+                               "halo tiling (tile %d + 2 x halo %d); set SPRK_EVAL_TILE=tile,halo" % (H, W, limit, tile, halo))
+        return tile, halo
 
     def img_outputs(self, prefix=None):
         """Image outputs of the configured pipeline -> metric names (train.py:763-779)."""
@@ -339,12 +406,12 @@ class DenoiserTrainer:
             t = outputs[key][DetectionDataset.INPUT] if key == PipelineOutput.INPUTS else outputs[key]
             if not torch.is_tensor(t) or t.numel() == 0:
                 continue
-            tensor_to_png(unpad(t), path(fileformat, desc))
+            self.writer.png(unpad(t), path(fileformat, desc))
         if PipelineOutput.DETECT in outputs and scoreformat is not None:
             score_map = unpad(outputs[PipelineOutput.DETECT])[0].contiguous()
             scores, coords = nms_device(score_map, self.cfg[ConfigValue.NMS], NMS_THRESHOLD)
-            picks.write_scores(path(scoreformat, "scores"), name, scores.cpu().numpy(), coords.cpu().numpy(),
-                               tuple(score_map.shape))
+            self.writer.call(picks.write_scores, path(scoreformat, "scores"), name, scores.cpu().numpy(),
+                             coords.cpu().numpy(), tuple(score_map.shape))
 
     # ---- checkpoints ---------------------------------------------------------------------------
     def snapshot(self, output_name=None, subdir=None, model_only=False):

@@ -178,11 +178,15 @@ def test_three_graph_steps_with_multiadam_equal_three_eager_steps_with_torch_ada
     from spr_pick_amd.params import PipelineOutput as P
     gws = [golden("joint_train_w.npz"), golden("joint_train_h.npz")]
     steps = [(gws[0], 0.3), (gws[1], 0.8), (gws[0], 0.6)]
-    a, b = _denoiser(oracle_state, dtype), _denoiser(oracle_state, dtype)
+    a, b, c = _denoiser(oracle_state, dtype), _denoiser(oracle_state, dtype), _denoiser(oracle_state, dtype)
     B = gws[0]["inp"].shape[0]
     st = graph_step.GraphedTrainStep(a, B, 64, 0.75, 0.01, draw_eps=False, eager_warmup=1)
     opt_a = graph_step.make_adam([p for p in a.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99))
     opt_b = torch.optim.Adam([p for p in b.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99))
+    # third loop: torch.optim.Adam driven with the STEPPER'S OWN gradients — only the Adam arithmetic differs from loop a
+    opt_c = torch.optim.Adam([p for p in c.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.99))
+    hist_a, hist_b = {}, {}
+    solid = {}          # per parameter: elements whose |g| exceeded 1e-4 max|g| of their tensor in EVERY step (loop a)
     init = {k: v.clone() for k, v in a.state_dict().items() if torch.is_tensor(v)}
     g0 = gws[0]
     st.prepare(torch.from_numpy(g0["inp"]).cuda(), torch.from_numpy(g0["target"]), torch.from_numpy(g0["eps"]).cuda(),
@@ -194,7 +198,16 @@ def test_three_graph_steps_with_multiadam_equal_three_eager_steps_with_torch_ada
         eps, epf = torch.from_numpy(g["eps"]).cuda(), torch.from_numpy(g["eps_flip"]).cuda()
         o = st(inp, tgt, flip_p=p, eps=eps, eps_flip=epf)
         la = o[P.LOSS].detach().clone()
+        for (n, pa), (_, pc) in zip(a.named_parameters(), c.named_parameters()):
+            pc.grad = None if pa.grad is None else pa.grad.detach().clone()
+            # ("solid": tensors of more than one element — the one-element detector.m.{weight,bias} sit in front of another
+            # BatchNorm, their true gradient is ZERO and what they receive is rounding noise whose sign differs per loop)
+            if pa.grad is not None and pa.numel() > 1:
+                m = pa.grad.abs() > 1e-4 * pa.grad.abs().max()
+                solid[n] = m if n not in solid else (solid[n] & m)
+                hist_a.setdefault(n, []).append(pa.grad.detach().clone())
         opt_a.step()
+        opt_c.step()
         opt_b.zero_grad(set_to_none=True)
         ob = b.run_pipeline(DetectionDataset.make_batch(inp, tgt), 0.75, 0.01, train=True, eps=eps, eps_flip=epf, flip_p=p)
         torch.mean(ob[P.LOSS]).backward()
@@ -203,6 +216,9 @@ def test_three_graph_steps_with_multiadam_equal_three_eager_steps_with_torch_ada
             for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
                 assert (pa.grad is None) == (pb.grad is None), n
                 assert pa.grad is None or torch.equal(pa.grad, pb.grad), n
+        for n, pb in b.named_parameters():
+            if pb.grad is not None:
+                hist_b.setdefault(n, []).append(pb.grad.detach().clone())
         opt_b.step()
         losses.append((la, ob[P.LOSS].detach().clone()))
         if it == 0:
@@ -221,13 +237,37 @@ def test_three_graph_steps_with_multiadam_equal_three_eager_steps_with_torch_ada
     # one element of decode_block_1.0.weight, i.e. 4 % of the 3e-4 the three steps can move a weight; 99.9 % of all
     # elements agree to 1e-6.
     moved, worst, n_el, n_off = 0.0, 0.0, 0, 0
-    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+    worst_solid, n_solid, worst_adam = 0.0, 0, 0.0
+    for (n, pa), (_, pb), (_, pc) in zip(a.named_parameters(), b.named_parameters(), c.named_parameters()):
         d = (pa.detach() - pb.detach()).abs()
         worst = max(worst, float(d.max()))
         n_el += d.numel()
         n_off += int((d > 1e-6).sum())
         moved = max(moved, float((pa.detach() - init[n].to(pa.device)).abs().max()))
-    print("%s: max parameter difference after 3 steps %.2e, %d of %d elements beyond 1e-6" % (dtype, worst, n_off, n_el))
+        worst_adam = max(worst_adam, float((pa.detach() - pc.detach()).abs().max()))
+        if n in solid and bool(solid[n].any()):
+            ws = float(d[solid[n]].max())
+            if ws > 1e-6:
+                k = int(torch.argmax(d * solid[n]))
+                print("  solid offender %s[%d]: |d| %.2e; gradient history a %s b %s; tensor max|g| %s" % (
+                    n, k, ws, ["%.2e" % float(g.reshape(-1)[k]) for g in hist_a[n]], ["%.2e" % float(g.reshape(-1)[k]) for g in hist_b[n]],
+                    ["%.2e" % float(g.abs().max()) for g in hist_a[n]]))
+            worst_solid = max(worst_solid, ws)
+            n_solid += int(solid[n].sum())
+    print("%s: max parameter difference after 3 steps %.2e, %d of %d elements beyond 1e-6; over the %d elements whose "
+          "gradient stayed above 1e-4 max|g|: %.2e; same gradients through torch.optim.Adam vs MultiAdam: %.2e" % (
+              dtype, worst, n_off, n_el, n_solid, worst_solid, worst_adam))
+    # (1) same gradients, two Adam implementations: three updates differ by rounding only
+    assert worst_adam <= 5e-6, "MultiAdam vs torch.optim.Adam on identical gradients: %.3e after three steps" % worst_adam
+    # (2) independent loops: wherever the gradient is not at the noise floor, the loops agree
+    assert n_solid >= n_el // 10, (n_solid, n_el)
+    if dtype == "f32":
+        # measured 1.2e-5 (decode_block_1.0.weight: its third-step gradient is 2.8e-2 in one loop and 3.7e-2 in the other —
+        # the randomly initialised fixture divides by predicted variances near zero, so parameters that differ by 2e-7 after
+        # the first update give visibly different gradients two steps later; printed above).  Three updates of <= 1e-4 each
+        # could move an element by 3e-4: the bound below is 10 % of that, over 85 % of all elements.
+        assert worst_solid <= 3e-5, ("elements with |g| > 1e-4 max|g| in all three steps differ by %.3e (max over %d elements)"
+                                     % (worst_solid, n_solid))
     if dtype == "f32":
         # (worst case: the two updates after the first differ by their full size, 2 x 1e-4; measured 4e-5 .. 1e-4 depending
         # on the summation order of the backward-weight partial sums)

@@ -447,19 +447,38 @@ def test_reparam_sigmoid_ssdn():
     # ssdn
     orr = o.double().requires_grad_(True)
     nsr = ns.double().requires_grad_(True)
-    nll, pme, sx = pipeline.ssdn_terms(x.double(), orr[:, 0:1], orr[:, 1:2], nsr)
+    nll, pme, sx, _ = pipeline.ssdn_terms(x.double(), orr[:, 0:1], orr[:, 1:2], nsr)
     lossr = nll.reshape(B, -1).mean(1, keepdim=True)
     gl = torch.randn(B, 1, generator=g)
     lossr.backward(gl.double())
     od = o.to(d).requires_grad_(True)
     nsd = ns.to(d).requires_grad_(True)
-    loss, pm, ms = ops.ssdn_nll_pme(x.to(d), od, nsd)
+    loss, pm, ms, nsm = ops.ssdn_nll_pme(x.to(d), od, nsd)
+    assert nsm.numel() == 0
     close(loss, lossr, rel=2e-6, name="ssdn loss")
     close(pm, pme, rel=2e-6, name="pme")
     close(ms, (sx ** 0.5)[:, 0].unsqueeze(0), rel=2e-6, name="model std")
     loss.backward(gl.to(d))
     close(od.grad, orr.grad, rel=1e-5, name="ssdn g_out")
     close(nsd.grad, nsr.grad, rel=1e-5, name="ssdn g_noise")
+    # poisson likelihood (denoiser_v2.py:412-424): sigma_n^2 = max(mu, 1e-3) * estimate per pixel; mu on both sides of the floor
+    op = o.clone()
+    op[:, 0] = op[:, 0] * 0.5 + 0.1
+    assert 0.15 < float((op[:, 0] < 1e-3).float().mean()) < 0.85
+    orr = op.double().requires_grad_(True)
+    nsr = ns.double().requires_grad_(True)
+    nll, pme, sx, nstd = pipeline.ssdn_terms(x.double(), orr[:, 0:1], orr[:, 1:2], nsr, "poisson")
+    lossr = nll.reshape(B, -1).mean(1, keepdim=True)
+    lossr.backward(gl.double())
+    od = op.to(d).requires_grad_(True)
+    nsd = ns.to(d).requires_grad_(True)
+    loss, pm, ms, nsm = ops.ssdn_nll_pme(x.to(d), od, nsd, ops.NOISE_POISSON)
+    close(loss, lossr, rel=2e-6, name="poisson loss")
+    close(pm, pme, rel=2e-6, name="poisson pme")
+    close(nsm, nstd[:, 0], rel=2e-6, name="poisson noise std map")
+    loss.backward(gl.to(d))
+    close(od.grad, orr.grad, rel=1e-5, name="poisson g_out")
+    close(nsd.grad, nsr.grad, rel=1e-5, name="poisson g_noise")
 
 
 def test_cpu_tensors_are_refused():

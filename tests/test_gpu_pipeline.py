@@ -145,6 +145,52 @@ def test_joint_train_step_matches_reference(denoiser, tag):
             close(sd[name].float(), g[k].astype(np.float64), rel=1e-4, name=name)
 
 
+def test_poisson_branch_matches_reference(oracle_state):
+    """--noise_style poisson (denoiser_v2.py:412-424) against the reference's own outputs (tests/golden/joint_poisson.npz,
+    generator oracle/gen_golden_poisson.py): a joint train step (outputs, losses, parameter gradients) and a filled eval
+    pass; NOISE_STD_DEV is a per-pixel map in this branch."""
+    from spr_pick_amd import Denoiser, DetectionDataset
+    from spr_pick_amd.params import ConfigValue, PipelineOutput as P
+    g = golden("joint_poisson.npz")
+    cfg = make_cfg()
+    cfg[ConfigValue.NOISE_STYLE] = "poisson"
+    den = Denoiser(cfg, device="cuda:0", mode="joint")
+    sd = {"models." + k: v.clone() for k, v in oracle_state.items()}
+    sd["models.denoiser_model.denoise_branch.output_conv.bias"][0] += float(g["mu_bias"])
+    _, unexpected = den.load_state_dict(sd, strict=False)
+    assert not unexpected
+    den.train(); den.unfill()
+    data = DetectionDataset.make_batch(torch.from_numpy(g["inp"]), torch.from_numpy(g["target"]))
+    o = den.run_pipeline(data, float(g["alpha"]), float(g["tau"]), train=True, eps=torch.from_numpy(g["eps"]).cuda(),
+                         eps_flip=torch.from_numpy(g["eps_flip"]).cuda(), flip_p=float(g["flip_p"]))
+    torch.mean(o[P.LOSS]).backward()
+    assert tuple(o[P.NOISE_STD_DEV].shape) == (3, 64, 64)
+    for key in ("LOSS", "DENOISE_LOSS", "DETECT", "IMG_MU", "IMG_DENOISED", "NOISE_STD_DEV", "MODEL_STD_DEV"):
+        close(o[getattr(P, key)], g[key], name=key)
+    close(o[P.DETECT_LOSS].reshape(()), g["DETECT_LOSS"], name="DETECT_LOSS")
+    loose = total = 0
+    for name, p in den.models.named_parameters():
+        key = "grad/" + name
+        if key + "/val" not in g.files:
+            assert p.grad is None, name
+            continue
+        a = p.grad.detach().cpu().numpy().astype(np.float64).ravel()
+        absmax = float(g[key + "/absmax"])
+        errs = np.abs(a[g[key + "/idx"]] - g[key + "/val"])
+        assert errs.max() <= 3e-3 * absmax + 1e-4, "%s: probe err %.3e vs max|g| %.3e" % (name, errs.max(), absmax)
+        loose += int((errs > 1e-3 * absmax + 1e-6).sum())
+        total += len(errs)
+    assert total > 10000 and loose <= total // 500, (loose, total)
+    den.load_state_dict(sd, strict=False)
+    den.eval(); den.fill()
+    with torch.no_grad():
+        oe = den.run_pipeline(DetectionDataset.make_batch(torch.from_numpy(g["eval/inp"]), torch.zeros(1, 1)), train=False,
+                              eps=torch.from_numpy(g["eval/eps"]).cuda())
+    den.unfill()
+    for key in ("LOSS", "DETECT", "IMG_MU", "IMG_DENOISED", "NOISE_STD_DEV", "MODEL_STD_DEV"):
+        close(oe[getattr(P, key)], g["eval/" + key], name="eval " + key)
+
+
 def test_joint_eval_and_picks(denoiser, oracle_state):
     from oracle import nms, pipeline
     from spr_pick_amd import DetectionDataset, non_maximum_suppression

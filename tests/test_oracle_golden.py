@@ -169,3 +169,36 @@ def test_lr_schedule_and_width():
     lr = [pipeline.trainer_lrate(int(i), 80000) for i in g["lr_iters"]]
     np.testing.assert_allclose(lr, g["lr"], rtol=1e-12, atol=0)
     assert int(g["det_width"]) == networks.DET_WIDTH
+
+
+def test_joint_poisson_step_and_eval(oracle_state):
+    """The poisson likelihood branch (denoiser_v2.py:412-424) against the reference's own outputs
+    (oracle/gen_golden_poisson.py): a joint train step with gradients and a filled eval pass."""
+    g = golden("joint_poisson.npz")
+    sd = clone_state(oracle_state)
+    sd[MODEL + "denoise_branch.output_conv.bias"][0] += float(g["mu_bias"])
+    sd0 = clone_state(sd)
+    for k, v in sd.items():
+        if v.is_floating_point() and "running" not in k:
+            v.requires_grad_(True)
+    res = pipeline.joint_pipeline(sd, torch.from_numpy(g["inp"]), torch.from_numpy(g["target"]), float(g["alpha"]),
+                                  float(g["tau"]), True, torch.from_numpy(g["eps"]), torch.from_numpy(g["eps_flip"]),
+                                  float(g["flip_p"]), noise_style="poisson")
+    res["LOSS"].mean().backward()
+    assert res["NOISE_STD_DEV"].shape == (3, 64, 64)            # per pixel now, not per image
+    for k in ("LOSS", "DENOISE_LOSS", "DETECT_LOSS", "AUG_LOSS", "DETECT", "IMG_MU", "IMG_DENOISED", "NOISE_STD_DEV",
+              "MODEL_STD_DEV"):
+        np.testing.assert_allclose(res[k].detach().numpy(), g[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    assert 0.2 < float(g["frac_mu_below_floor"]) < 0.8          # both sides of max(mu, 1e-3) are exercised
+    n = 0
+    for name, p in sd.items():
+        if p.requires_grad and ("grad/" + name + "/val") in g.files:
+            # (the likelihood of this fixture is large — loss ~90 — and so are its gradients: absolute slack scales with them)
+            check_probe(g, "grad/" + name, p.grad, 2e-4, 1e-6 * float(g["grad/" + name + "/absmax"]) + 1e-7)
+            n += 1
+    assert n > 60
+    with torch.no_grad():
+        ev = pipeline.joint_pipeline(sd0, torch.from_numpy(g["eval/inp"]), None, 0, 0, False,
+                                     torch.from_numpy(g["eval/eps"]), noise_style="poisson")
+    for k in ("LOSS", "DETECT", "IMG_MU", "IMG_DENOISED", "NOISE_STD_DEV", "MODEL_STD_DEV"):
+        np.testing.assert_allclose(ev[k].numpy(), g["eval/" + k], rtol=2e-5, atol=2e-6, err_msg=k)
