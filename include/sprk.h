@@ -75,6 +75,18 @@ typedef struct sprk_conv_geom {
  * halo-tiled inference set it, so that a window of a micrograph is computed by exactly the arithmetic the whole
  * micrograph gets (bit-identical score maps, hence identical picks; tests/test_gpu_pipeline.py). */
 #define SPRK_DT_PIN 0x400
+/* 16-bit ACTIVATION tensors in HBM (round 4; BASELINE configs[4]).  With SPRK_DT_BF16 / SPRK_DT_F16 alone the tensors of
+ * a call are fp32 and only the MFMA operands are rounded on their way in.  SPRK_DT_X16: the activation INPUTS of the call —
+ * x and x2 of a forward call, gy of backward-data, x, x2 AND gy of backward-weight — are tensors of the operand type
+ * (the `const float *` parameters then point at 2-byte elements).  SPRK_DT_Y16: the activation OUTPUT — y of forward,
+ * gin (and mask_y) of backward-data — is such a tensor: the fp32 accumulator is rounded once, at the store.  Weights,
+ * biases, weight gradients and all arithmetic stay fp32.  Only the kernels built for it take these calls
+ * (sprk_conv2d_storage16 tells which of a layer's three calls exist); any other geometry returns SPRK_EINVAL. */
+#define SPRK_DT_X16 0x8000
+#define SPRK_DT_Y16 0x10000
+/* element types of the tensors of an elementwise call, 4 bits each: SPRK_DT_F32 / _BF16 / _F16 */
+#define SPRK_IO2(a, b) ((a) | ((b) << 4))
+#define SPRK_IO3(a, b, c) ((a) | ((b) << 4) | ((c) << 8))
 
 /* Optional fused epilogue of sprk_conv2d_fwd, applied in this order:
  *   v = acc (+ res[n,co,oy+res_off,ox+res_off])            res: [N,Cout,res_h,res_w]
@@ -152,6 +164,9 @@ int sprk_head1x1_unrot_fwd(const float *d, const float *w1, const float *b1, con
  * other kernels finish with an in-place pass, so the call is valid for every geometry without upsampled input. */
 int sprk_conv2d_bwd_data_masked(const float *gy, const float *w, float *gin, const sprk_conv_geom *g,
                                 const float *mask_y, int mask_act, void *ws, size_t ws_bytes, void *stream);
+/* bit 0 / 1 / 2: the forward / backward-data / backward-weight call of this layer exists for 16-bit activation tensors
+ * (SPRK_DT_X16 / SPRK_DT_Y16; g->dtype carries the operand type, ep the forward epilogue or NULL) */
+int sprk_conv2d_storage16(const sprk_conv_geom *g, const sprk_conv_epilogue *ep);
 /* gw[Cout][C1+C2][KH][KW] = d loss / d w  (overwritten, not accumulated) */
 size_t sprk_conv2d_bwd_weight_ws_bytes(const sprk_conv_geom *g);
 int sprk_conv2d_bwd_weight(const float *x, const float *x2, const float *gy, float *gw,
@@ -190,8 +205,11 @@ size_t sprk_act_bwd_ws_bytes(int N, int C, int HW);
 /* g_image_stride: elements between consecutive images of gy, 0 = dense (C*H*W, or 4*C*H*W with up2).  A larger
  * stride reads gy out of a channel slice of a wider tensor (the two halves of a concat layer's input gradient are
  * handed on as views); y and gpre are always dense. */
-int sprk_act_bwd(const float *gy, const float *y, float *gpre, float *gbias, int act,
-                 int N, int C, int H, int W, int up2, long g_image_stride,
+/* io = SPRK_IO3(type of gy, type of y, type of gpre): every tensor fp32 or the call's 16-bit type (all bf16 or all fp16);
+ * gbias and the arithmetic are fp32.  With act == NONE and different gy / gpre types the call is a change of storage
+ * type (+ the bias sum). */
+int sprk_act_bwd(const void *gy, const void *y, void *gpre, float *gbias, int act,
+                 int N, int C, int H, int W, int up2, long g_image_stride, int io,
                  void *ws, size_t ws_bytes, void *stream);
 /* ---- deferred second-stage reductions ------------------------------------------------------
  * Backward-weight and the bias gradient are two-stage sums: the main kernel leaves per-workgroup partial sums in
@@ -213,8 +231,8 @@ typedef struct sprk_reduce_item {
 int sprk_conv2d_bwd_weight_partial(const float *x, const float *x2, const float *gy, float *gw,
                                    const sprk_conv_geom *g, void *ws, size_t ws_bytes,
                                    sprk_reduce_item *item, void *stream);
-int sprk_act_bwd_partial(const float *gy, const float *y, float *gpre, float *gbias, int act,
-                         int N, int C, int H, int W, int up2, long g_image_stride,
+int sprk_act_bwd_partial(const void *gy, const void *y, void *gpre, float *gbias, int act,
+                         int N, int C, int H, int W, int up2, long g_image_stride, int io,
                          void *ws, size_t ws_bytes, sprk_reduce_item *item, void *stream);
 /* every sum: four interleaved chains over p (p mod 4), combined as (s0 + s1) + (s2 + s3) */
 int sprk_reduce_items(const sprk_reduce_item *items, int n, void *stream);
@@ -227,19 +245,21 @@ int sprk_concat_up_bwd(const float *gin, float *ga, float *gb, int N, int C1, in
 /* ---- U-Net plumbing (HBM-bound) --------------------------------------------------------
  * Shift2d((1,0)) + MaxPool2d(2): models/joint_network_v2.py:27-30, models/utility.py:46-72;
  * shift = 0 gives the plain MaxPool2d(2) of the sigma net (joint_network_v2_shallow.py). */
-int sprk_shift_maxpool2_fwd(const float *x, float *y, int NC, int H, int W, int shift, void *stream);
+/* io = SPRK_IO2(type of x, type of y) / SPRK_IO3(type of gy, type of x, type of gx) */
+int sprk_shift_maxpool2_fwd(const void *x, void *y, int NC, int H, int W, int shift, int io, void *stream);
 /* act != SPRK_ACT_NONE: x is the post-activation output of a convolution consumed by this pool only; gx is multiplied
  * by act'(x) and is then that convolution's PRE-activation gradient (its sprk_act_bwd pass reduces to the bias sum) */
-int sprk_shift_maxpool2_bwd(const float *gy, const float *x, float *gx, int NC, int H, int W, int shift, int act,
-                            void *stream);
+int sprk_shift_maxpool2_bwd(const void *gy, const void *x, void *gx, int NC, int H, int W, int shift, int act,
+                            int io, void *stream);
 /* rotate(x,{0,90,180,270}) + cat(dim=0): joint_network_v2.py:198-200, utils/data.py:43-68.
  * x [B,C,P,P] -> y [4B,C,P,P]; bwd sums the four inverse rotations into gx. */
 int sprk_rot4_stack_fwd(const float *x, float *y, int B, int C, int P, void *stream);
 int sprk_rot4_stack_bwd(const float *gy, float *gx, int B, int C, int P, void *stream);
 /* Shift2d((1,0)) + chunk(4) + rotate({0,270,180,90}) + cat(dim=1): joint_network_v2.py:230-239.
  * d [4B,C,P,P] -> f [B,4C,P,P] */
-int sprk_unrot4_shift_concat_fwd(const float *d, float *f, int B, int C, int P, void *stream);
-int sprk_unrot4_shift_concat_bwd(const float *gf, float *gd, int B, int C, int P, void *stream);
+/* io = SPRK_IO2(type of the input, type of the output) */
+int sprk_unrot4_shift_concat_fwd(const void *d, void *f, int B, int C, int P, int io, void *stream);
+int sprk_unrot4_shift_concat_bwd(const void *gf, void *gd, int B, int C, int P, int io, void *stream);
 
 /* ---- BatchNorm2d (+ optional ReLU), detector: joint_network_v2.py:547,558;
  * feature_extractor.py:287-288,320-324,338-346,412-414.

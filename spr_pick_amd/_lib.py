@@ -10,6 +10,7 @@ ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2          # SPRK_DT_*: precision of the MFMA operands (include/sprk.h)
 DT_NAIVE = 0x200                           # SPRK_DT_NAIVE: plain per-output-element kernels for this call (cross-check)
 DT_WPREP = 0x800                           # SPRK_DT_WPREP: the workspace already holds the transformed weights
+DT_X16, DT_Y16 = 0x8000, 0x10000           # SPRK_DT_X16 / _Y16: the activation inputs / the output of a call are 16-bit tensors
 DT_PIN = 0x400                             # SPRK_DT_PIN: kernel choice by layer structure only (inference: tiled == whole)
 DT_FORCE = 0x100                           # SPRK_DT_FORCE: 16-bit kernel wherever it exists (tests), not only where faster
 DTYPES = {"f32": DT_F32, "fp32": DT_F32, "bf16": DT_BF16, "f16": DT_F16, "fp16": DT_F16,
@@ -69,19 +70,20 @@ _SIGS = {
     "sprk_conv2d_bwd_data": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_data_masked": (c_i, [c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_f, c_i, c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_weight_ws_bytes": (c_sz, [ctypes.POINTER(ConvGeom)]),
+    "sprk_conv2d_storage16": (c_i, [ctypes.POINTER(ConvGeom), ctypes.POINTER(ConvEpilogue)]),
     "sprk_conv2d_bwd_weight": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, c_vp]),
     "sprk_conv2d_bwd_weight_partial": (c_i, [c_f, c_f, c_f, c_f, ctypes.POINTER(ConvGeom), c_vp, c_sz, ctypes.POINTER(ReduceItem), c_vp]),
-    "sprk_act_bwd_partial": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_long, c_vp, c_sz, ctypes.POINTER(ReduceItem), c_vp]),
+    "sprk_act_bwd_partial": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_long, c_i, c_vp, c_sz, ctypes.POINTER(ReduceItem), c_vp]),
     "sprk_reduce_items": (c_i, [ctypes.POINTER(ReduceItem), c_i, c_vp]),
     "sprk_act_bwd_ws_bytes": (c_sz, [c_i, c_i, c_i]),
-    "sprk_act_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_long, c_vp, c_sz, c_vp]),
+    "sprk_act_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, ctypes.c_long, c_i, c_vp, c_sz, c_vp]),
     "sprk_concat_up_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
-    "sprk_shift_maxpool2_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),
-    "sprk_shift_maxpool2_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "sprk_shift_maxpool2_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "sprk_shift_maxpool2_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
     "sprk_rot4_stack_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
     "sprk_rot4_stack_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
-    "sprk_unrot4_shift_concat_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
-    "sprk_unrot4_shift_concat_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_vp]),
+    "sprk_unrot4_shift_concat_fwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),
+    "sprk_unrot4_shift_concat_bwd": (c_i, [c_f, c_f, c_i, c_i, c_i, c_i, c_vp]),
     "sprk_bn_ws_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "sprk_bn_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_i, c_vp, c_sz, c_vp]),
     "sprk_bn_eval_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_vp]),

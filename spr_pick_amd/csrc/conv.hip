@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "conv_dev.h"
+#include "io_dev.h"
 
 
 namespace {
@@ -817,7 +818,10 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_direct_kernel(const Direc
 // epilogue; the incoming gradient is first summed over each 2x2 block (backward of nn.Upsample).
 // gstride: elements between consecutive images of g (a channel slice of a wider tensor: the backward-data output of
 // a concat layer is handed on as views, not copied); y and gpre are dense.
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const float *__restrict__ y, float *gpre,
+// TG / TY / TO: element types of g, y and gpre (fp32 or the 16-bit storage type, io_dev.h); arithmetic and the bias
+// sums are fp32.
+template <typename TG, typename TY, typename TO>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const TG *g, const TY *__restrict__ y, TO *gpre,
                                                       float *__restrict__ partial, int act, int N, int C, int HW,
                                                       int W, int up2, int nsplit, long gstride) {
     const int c = blockIdx.x, s = blockIdx.y;
@@ -828,37 +832,39 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const floa
     for (int n = s; n < N; n += nsplit) {
         const long base = ((long)n * C + c) * HW;
         const long gbase = (long)n * gstride + (long)c * (up2 ? 4L * HW : HW);     // first element of g's plane
-        if (v4) {  // 16 bytes per lane
+        if (v4) {  // four elements per lane
             for (int i = threadIdx.x * 4; i < HW; i += 1024) {
-                float4 v = *reinterpret_cast<const float4 *>(g + gbase + i);
+                float4 v = IO<TG>::ld4(g + gbase + i);
                 if (act != SPRK_ACT_NONE) {
-                    const float4 yv = *reinterpret_cast<const float4 *>(y + base + i);
+                    const float4 yv = IO<TY>::ld4(y + base + i);
                     const bool lk = act == SPRK_ACT_LEAKY;
                     v.x = yv.x > 0.f ? v.x : (lk ? v.x * kLeak : 0.f);
                     v.y = yv.y > 0.f ? v.y : (lk ? v.y * kLeak : 0.f);
                     v.z = yv.z > 0.f ? v.z : (lk ? v.z * kLeak : 0.f);
                     v.w = yv.w > 0.f ? v.w : (lk ? v.w * kLeak : 0.f);
-                    *reinterpret_cast<float4 *>(gpre + base + i) = v;
+                    IO<TO>::st4(gpre + base + i, v);
+                } else if (IO<TG>::code != IO<TO>::code && gpre) {
+                    IO<TO>::st4(gpre + base + i, v);       // a pure change of storage type on the way (+ the bias sum)
                 }
                 sum += (v.x + v.y) + (v.z + v.w);
             }
             continue;
         }
-        if (v2u) {  // two outputs per lane: one float4 from each of the two source rows
+        if (v2u) {  // two outputs per lane: four elements from each of the two source rows
             for (int i = threadIdx.x * 2; i < HW; i += 512) {
                 const int oy = i / W, ox = i - oy * W;
                 const long q = base * 4 + (long)(2 * oy) * (2 * W) + 2 * ox;
                 const long gq = gbase + (long)(2 * oy) * (2 * W) + 2 * ox;
-                const float4 a = *reinterpret_cast<const float4 *>(g + gq);
-                const float4 b = *reinterpret_cast<const float4 *>(g + gq + 2 * W);
+                const float4 a = IO<TG>::ld4(g + gq);
+                const float4 b = IO<TG>::ld4(g + gq + 2 * W);
                 float2 v = make_float2((a.x + a.y) + (b.x + b.y), (a.z + a.w) + (b.z + b.w));
                 if (act != SPRK_ACT_NONE) {
-                    const float4 yv = *reinterpret_cast<const float4 *>(y + q);
+                    const float4 yv = IO<TY>::ld4(y + q);
                     const bool lk = act == SPRK_ACT_LEAKY;
                     v.x = yv.x > 0.f ? v.x : (lk ? v.x * kLeak : 0.f);
                     v.y = yv.z > 0.f ? v.y : (lk ? v.y * kLeak : 0.f);
                 }
-                *reinterpret_cast<float2 *>(gpre + base + i) = v;
+                IO<TO>::st2(gpre + base + i, v);
                 sum += v.x + v.y;
             }
             continue;
@@ -869,17 +875,17 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *g, const floa
                 const int oy = i / W, ox = i - oy * W;
                 const long q = base * 4 + (long)(2 * oy) * (2 * W) + 2 * ox;
                 const long gq = gbase + (long)(2 * oy) * (2 * W) + 2 * ox;
-                v = (g[gq] + g[gq + 1]) + (g[gq + 2 * W] + g[gq + 2 * W + 1]);
-                if (act != SPRK_ACT_NONE) yv = y[q];
+                v = (IO<TG>::ld(g + gq) + IO<TG>::ld(g + gq + 1)) + (IO<TG>::ld(g + gq + 2 * W) + IO<TG>::ld(g + gq + 2 * W + 1));
+                if (act != SPRK_ACT_NONE) yv = IO<TY>::ld(y + q);
             } else {
-                v = g[gbase + i];
-                if (act != SPRK_ACT_NONE) yv = y[base + i];
+                v = IO<TG>::ld(g + gbase + i);
+                if (act != SPRK_ACT_NONE) yv = IO<TY>::ld(y + base + i);
             }
             if (act == SPRK_ACT_LEAKY)
                 v = yv > 0.f ? v : v * kLeak;
             else if (act == SPRK_ACT_RELU)
                 v = yv > 0.f ? v : 0.f;
-            if (act != SPRK_ACT_NONE || up2) gpre[base + i] = v;
+            if (act != SPRK_ACT_NONE || up2 || (IO<TG>::code != IO<TO>::code && gpre)) IO<TO>::st(gpre + base + i, v);
             sum += v;
         }
     }
@@ -1280,6 +1286,7 @@ sprk::WinoGeom wino_geom_bwd(const sprk_conv_geom *g) {
 sprk::Conv16Call call16_fwd(const sprk_conv_geom *g, const sprk_conv_epilogue *ep) {
     sprk::Conv16Call c{};
     c.dtype = g->dtype; c.mode = 0;
+    c.x16 = (g->dtype & SPRK_DT_X16) ? 1 : 0; c.y16 = (g->dtype & SPRK_DT_Y16) ? 1 : 0;
     c.N = g->N; c.C1 = g->C1; c.C2 = g->C2; c.Hin = g->Hin; c.Win = g->Win; c.Cout = g->Cout; c.Hout = g->Hout;
     c.Wout = g->Wout; c.KH = g->KH; c.KW = g->KW; c.stride = g->stride; c.dil = g->dil; c.padT = g->pad_top;
     c.padL = g->pad_left; c.up1 = g->up1;
@@ -1294,6 +1301,7 @@ sprk::Conv16Call call16_fwd(const sprk_conv_geom *g, const sprk_conv_epilogue *e
 sprk::Conv16Call call16_bwd(const sprk_conv_geom *g) {
     sprk::Conv16Call c{};
     c.dtype = g->dtype; c.mode = 1;
+    c.x16 = (g->dtype & SPRK_DT_X16) ? 1 : 0; c.y16 = (g->dtype & SPRK_DT_Y16) ? 1 : 0;    // gy / gin
     c.N = g->N; c.C1 = g->Cout; c.C2 = 0; c.Hin = g->Hout; c.Win = g->Wout; c.Cout = g->C1 + g->C2; c.Hout = g->Hin;
     c.Wout = g->Win; c.KH = g->KH; c.KW = g->KW; c.stride = g->stride; c.dil = g->dil;
     c.padT = (g->KH - 1) * g->dil - g->pad_top; c.padL = (g->KW - 1) * g->dil - g->pad_left; c.up1 = g->up1;
@@ -1306,6 +1314,7 @@ sprk::Conv16Call call16_bwd(const sprk_conv_geom *g) {
 sprk::Wgrad16Call call16_wgrad(const sprk_conv_geom *g) {
     sprk::Wgrad16Call c{};
     c.dtype = g->dtype;
+    c.x16 = (g->dtype & SPRK_DT_X16) ? 1 : 0;
     c.N = g->N; c.C1 = g->C1; c.C2 = g->C2; c.H = g->Hin; c.W = g->Win; c.Cout = g->Cout; c.Hout = g->Hout;
     c.Wout = g->Wout; c.KH = g->KH; c.KW = g->KW; c.stride = g->stride; c.dil = g->dil; c.padT = g->pad_top;
     c.padL = g->pad_left; c.up1 = g->up1;
@@ -1328,6 +1337,22 @@ constexpr int kClassWino = 3;   // profiling class of the 96-channel Winograd ke
 // C ABI
 // ==========================================================================================
 extern "C" {
+
+// Which calls of a layer exist for 16-bit ACTIVATION tensors (SPRK_DT_X16 / SPRK_DT_Y16)?  Bit 0: forward, bit 1:
+// backward-data, bit 2: backward-weight.  g->dtype carries the operand type; the storage bits are ignored (every
+// input / output storage combination of an eligible call exists).  ep: the forward call's epilogue (may be null).
+int sprk_conv2d_storage16(const sprk_conv_geom *g, const sprk_conv_epilogue *ep) {
+    if (!g || check_geom(g) != SPRK_OK) return 0;
+    const int dt = g->dtype & SPRK_DT_MASK;
+    if ((dt != SPRK_DT_BF16 && dt != SPRK_DT_F16) || naive_of(g) || g->stride != 1) return 0;
+    sprk_conv_geom q = *g;
+    q.dtype = (g->dtype & ~(SPRK_DT_WPREP | SPRK_DT_WPREP_KIND(7))) | SPRK_DT_X16 | SPRK_DT_Y16;
+    int r = 0;
+    if (sprk::conv16_kind(call16_fwd(&q, ep)) >= 2) r |= 1;
+    if (!g->up1 && sprk::conv16_kind(call16_bwd(&q)) >= 2) r |= 2;
+    if (sprk::wgrad16_eligible(call16_wgrad(&q))) r |= 4;
+    return r;
+}
 
 size_t sprk_conv2d_fwd_ws_bytes(const sprk_conv_geom *g) {
     if (!g) return 0;
@@ -1386,6 +1411,8 @@ static int conv2d_fwd_impl(const float *x, const float *x2, const float *w, floa
         const sprk::Conv16Call c16 = call16_fwd(g, ep);
         if (sprk::conv16_eligible(c16)) return sprk::conv16_run(c16, x, x2, w, y, ws, ws_bytes, s);
     }
+    SPRK_REQUIRE(!(g->dtype & (SPRK_DT_X16 | SPRK_DT_Y16)),
+                 "conv2d_fwd: no kernel takes this geometry with 16-bit activation tensors (ask sprk_conv2d_storage16 first)");
     if (sprk::wino_eligible(wino_geom_fwd(g, ep)) && !ep->res) {
         const size_t need = sprk::wino_ws_bytes(g->C1, g->C2, g->Cout);
         if (ws_bytes < need || !ws) {
@@ -1446,8 +1473,11 @@ int sprk_conv2d_bwd_data(const float *gy, const float *w, float *gin, const sprk
 }
 
 // in-place mask of a finished gradient (the layers whose backward-data kernel has no masked epilogue)
+// (with SPRK_DT_Y16 the gradient and the mask — the consumer's saved 16-bit input — are tensors of the operand type)
 static int mask_in_place(float *gin, const float *mask_y, int mask_act, const sprk_conv_geom *g, hipStream_t s) {
-    return sprk_act_bwd(gin, mask_y, gin, nullptr, mask_act, g->N, g->C1 + g->C2, g->Hin, g->Win, 0, 0, nullptr, 0, s);
+    const int t = (g->dtype & SPRK_DT_Y16) ? (g->dtype & SPRK_DT_MASK) : 0;
+    return sprk_act_bwd(gin, mask_y, gin, nullptr, mask_act, g->N, g->C1 + g->C2, g->Hin, g->Win, 0, 0, SPRK_IO3(t, t, t),
+                        nullptr, 0, s);
 }
 
 static int conv2d_bwd_data_impl(const float *gy, const float *w, float *gin, const sprk_conv_geom *g,
@@ -1494,6 +1524,8 @@ static int conv2d_bwd_data_impl(const float *gy, const float *w, float *gin, con
             return mask_y ? mask_in_place(gin, mask_y, mask_act, g, s) : (int)SPRK_OK;
         }
     }
+    SPRK_REQUIRE(!(g->dtype & (SPRK_DT_X16 | SPRK_DT_Y16)),
+                 "conv2d_bwd_data: no kernel takes this geometry with 16-bit activation tensors (ask sprk_conv2d_storage16 first)");
     if (sprk::wino_eligible(wino_geom_bwd(g))) {
         const size_t need = sprk::wino_ws_bytes(g->Cout, 0, Cin);
         if (ws_bytes < need || !ws) {
@@ -1568,6 +1600,8 @@ int sprk_conv2d_bwd_weight_partial(const float *x, const float *x2, const float 
         const sprk::Wgrad16Call c16 = call16_wgrad(g);
         if (sprk::wgrad16_eligible(c16)) return sprk::wgrad16_run(c16, x, x2, gy, gw, ws, ws_bytes, item, s);
     }
+    SPRK_REQUIRE(!(g->dtype & (SPRK_DT_X16 | SPRK_DT_Y16)),
+                 "conv2d_bwd_weight: no kernel takes this geometry with 16-bit activation tensors (ask sprk_conv2d_storage16 first)");
     if (!naive_of(g) && sprk::wino_wgrad_eligible(wino_geom_fwd(g, nullptr))) {
         const size_t need = sprk::wino_wgrad_ws_bytes(g->C1, g->C2, g->Cout);
         if (ws_bytes < need || !ws) {
@@ -1660,19 +1694,22 @@ size_t sprk_act_bwd_ws_bytes(int N, int C, int HW) {
     return (size_t)C * act_nsplit(N, C) * sizeof(float);
 }
 
-int sprk_act_bwd(const float *g, const float *y, float *gpre, float *gbias, int act, int N, int C, int H, int W,
-                 int up2, long g_image_stride, void *ws, size_t ws_bytes, void *stream) {
-    return sprk_act_bwd_partial(g, y, gpre, gbias, act, N, C, H, W, up2, g_image_stride, ws, ws_bytes, nullptr, stream);
+int sprk_act_bwd(const void *g, const void *y, void *gpre, float *gbias, int act, int N, int C, int H, int W,
+                 int up2, long g_image_stride, int io, void *ws, size_t ws_bytes, void *stream) {
+    return sprk_act_bwd_partial(g, y, gpre, gbias, act, N, C, H, W, up2, g_image_stride, io, ws, ws_bytes, nullptr, stream);
 }
 
-int sprk_act_bwd_partial(const float *g, const float *y, float *gpre, float *gbias, int act, int N, int C, int H, int W,
-                         int up2, long g_image_stride, void *ws, size_t ws_bytes, sprk_reduce_item *item, void *stream) {
+int sprk_act_bwd_partial(const void *g, const void *y, void *gpre, float *gbias, int act, int N, int C, int H, int W,
+                         int up2, long g_image_stride, int io, void *ws, size_t ws_bytes, sprk_reduce_item *item,
+                         void *stream) {
     if (item) *item = sprk_reduce_item{nullptr, nullptr, SPRK_RED_NONE, 0, 0, 0, 0, 0};
     SPRK_REQUIRE(g && N > 0 && C > 0 && H > 0 && W > 0, "act_bwd: bad arguments");
     SPRK_REQUIRE(act == SPRK_ACT_NONE || (y && gpre), "act_bwd: activation needs the saved output and gpre");
     SPRK_REQUIRE(!up2 || (gpre && gpre != g), "act_bwd: up2 needs a separate low-resolution gpre");
     hipStream_t s = (hipStream_t)stream;
-    if (act == SPRK_ACT_NONE && !gbias && !up2) return SPRK_OK;
+    const bool retype = gpre && (io & 15) != ((io >> 8) & 15);    // gpre has another storage type than gy
+    SPRK_REQUIRE(!retype || gpre != g, "act_bwd: a change of storage type needs a separate gpre");
+    if (act == SPRK_ACT_NONE && !gbias && !up2 && !retype) return SPRK_OK;
     const int ns = act_nsplit(N, C);
     if (gbias && (ws_bytes < (size_t)C * ns * sizeof(float) || !ws)) {
         sprk::set_error("act_bwd: workspace too small");
@@ -1682,8 +1719,15 @@ int sprk_act_bwd_partial(const float *g, const float *y, float *gpre, float *gbi
     const long gs = g_image_stride ? g_image_stride : dense;
     SPRK_REQUIRE(gs >= dense, "act_bwd: image stride of gy smaller than one image");
     SPRK_REQUIRE(gs == dense || (gpre && gpre != g), "act_bwd: a strided gy needs a separate gpre");
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(C, ns), dim3(256), 0, s, g, y, gpre, gbias ? (float *)ws : nullptr, act, N, C,
-                       H * W, W, up2, ns, gs);
+    const int drc = dispatch_io3(io, [&](auto tg, auto ty, auto to) {
+        using TG = decltype(tg);
+        using TY = decltype(ty);
+        using TO = decltype(to);
+        hipLaunchKernelGGL((act_bwd_kernel<TG, TY, TO>), dim3(C, ns), dim3(256), 0, s, (const TG *)g, (const TY *)y, (TO *)gpre,
+                           gbias ? (float *)ws : nullptr, act, N, C, H * W, W, up2, ns, gs);
+        return 0;
+    });
+    SPRK_REQUIRE(drc == 0, "act_bwd: bad storage types (io)");
     if (int rc = sprk::check_launch("act_bwd")) return rc;
     if (gbias) {
         const sprk_reduce_item it{(const float *)ws, gbias, SPRK_RED_COLS, ns, C, 0, 0, 0};

@@ -1,11 +1,15 @@
 // 16-bit-operand convolutions of libsprk.so (gfx950 / MI355X): forward and backward-data of the U-Net layers on
 // v_mfma_f32_16x16x32_{bf16,f16} (BASELINE configs[4]: "fp16 MFMA conv").
 //
-// What is 16-bit and what is not.  Tensors stay fp32 in HBM (activations, gradients, master weights: the
-// reference's layout, checkpoints and optimiser are untouched); only the two MFMA operands are rounded to
-// bf16 / fp16 (round-to-nearest-even, v_cvt_pk_*), products are exact in fp32 and accumulated in fp32 by the
-// matrix core.  Per output the error is that of rounding each input once: |err| <= 2 u * sum|a_k w_k| with
+// What is 16-bit and what is not.  Master weights, accumulation and the epilogue arithmetic are fp32; the two MFMA
+// operands are bf16 / fp16 (round-to-nearest-even, v_cvt_pk_*), products are exact in fp32 and accumulated in fp32 by
+// the matrix core.  Per output the error is that of rounding each input once: |err| <= 2 u * sum|a_k w_k| with
 // u = 2^-8 (bf16) or 2^-11 (fp16), the unit roundoffs of 8 / 11 significant bits — the bound the parity tests use.
+// The ACTIVATION tensors in HBM are fp32 (SPRK_DT_BF16 / SPRK_DT_F16 alone: operands rounded on their way into the
+// matrix core) or, with SPRK_DT_X16 / SPRK_DT_Y16, tensors of the operand type themselves (round 4): the input is
+// then fetched two pixels per dword and goes to LDS without a conversion, the output is rounded once at the store —
+// half the bytes on both sides of kernels whose bound is HBM.  conv16_tile_kernel (3x3) and conv16_head_kernel (1x1)
+// exist in all four input / output storage combinations; conv16_mfma_kernel (small grids) is fp32-storage only.
 //
 // Same implicit GEMM as conv.hip:  Out[pixel][n] += A[pixel][k] * Wt[k][n],  k = (tap, channel).
 //   * the input tile (with halo, zeros outside the image) is staged exactly as in conv_mfma_kernel: fp32, by
@@ -256,6 +260,9 @@ struct Tile16Args {
     const void *w16;     // [nblk][nchunks][G4][NT16][8]
     int G4, nchunks, ngFull, ngLast, c8Last;
     int PX, PXP, inRows, inCols;   // halo pixels of a tile (all its images), padded to 16; halo rows / cols per image
+                                   // (16-bit input: inCols is the even-aligned column grid, see cshift)
+    int cshift;                    // 16-bit input: LDS column 0 is image column ix0 - cshift (an even column: pairs of
+                                   // pixels are fetched as aligned dwords); fp32 input: 0
     int ntiles;                    // imgGroups * tilesX * tilesY (workgroups are persistent over them)
     int diag;
 };
@@ -263,7 +270,8 @@ struct Tile16Args {
 constexpr int kTileThreads = 512;
 constexpr int kTileCK = 16;
 
-template <typename T, int NT>
+// X16 / Y16: the input tensors (both sources) / the output tensor are 16-bit tensors of type T instead of fp32.
+template <typename T, int NT, bool X16, bool Y16>
 __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16Args k) {
     using V8 = typename Op16<T>::v8;
     typedef const __attribute__((address_space(3))) V8 *lds_v8p;
@@ -285,27 +293,32 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
     const int TCm = (1 << a.lgTC) - 1, TRm = (1 << a.lgTR) - 1;
     const int ntiles = k.ntiles;
 
-    // ---- this thread's share of a tile fetch: up to 3 (channel group, halo pixel) items ------------------------------
-    // item i = tid + 512 r: channel group cg = i / P64 (wave-uniform: P64 is a multiple of 64), halo pixel i % P64.
+    // ---- this thread's share of a tile fetch: up to R (channel group, halo item) items --------------------------------
+    // fp32 input: an item is one halo pixel (8 channel loads of 4 bytes), R = 3.  16-bit input: an item is an aligned PAIR
+    // of halo pixels (8 channel loads of 4 bytes = 2 pixels each), R = 2.
+    // item i = tid + 512 r: channel group cg = i / P64 (wave-uniform: P64 is a multiple of 64), halo item i % P64.
     // Fixed per thread: the LDS slot and the halo position (image, row, column inside the tile); per tile: the offsets.
-    const int P64 = (k.PX + 63) & ~63;
+    constexpr int R = X16 ? 2 : 3, ES = X16 ? 2 : 4;
+    const int nItems = X16 ? k.PX >> 1 : k.PX;
+    const int P64 = (nItems + 63) & ~63;
     const int imgPix = k.inRows * k.inCols;
-    int wofs[3], hil[3], hrr[3], hcc[3];
+    int wofs[R], hil[R], hrr[R], hcc[R];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < R; ++r) {
         const int i = tid + r * kTileThreads;
-        const int cg = i / P64, px = i - cg * P64;
+        const int cg = i / P64, it = i - cg * P64;
         wofs[r] = -1;
         hil[r] = hrr[r] = hcc[r] = 0;
-        if (cg < 2 && px < k.PX) {
+        if (cg < 2 && it < nItems) {
+            const int px = X16 ? 2 * it : it;          // (inCols is even for 16-bit input: a pair never straddles rows)
             hil[r] = px / imgPix;
             const int rem = px - hil[r] * imgPix;
             hrr[r] = rem / k.inCols;
-            hcc[r] = rem - hrr[r] * k.inCols;
+            hcc[r] = rem - hrr[r] * k.inCols - k.cshift;
             wofs[r] = (cg * k.PXP + px) * 16;
         }
     }
-    int voff1[3], voff2[3];
+    int voff1[R], voff2[R];
     int n0 = 0, oy0 = 0, ox0 = 0;     // tile whose input is being fetched
     auto setup = [&](int t) {
         // contiguous runs of tiles per XCD (blocks b and b + 8 share an XCD and its L2; vertically adjacent tiles
@@ -323,23 +336,25 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
         oy0 = ty << a.lgTR; ox0 = tx << a.lgTC; n0 = ig * NI;
         const int iy0 = oy0 - a.padT, ix0 = ox0 - a.padL;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < R; ++r) {
+            // (16-bit input: ix is even and Win is even, so the pair is inside or outside the image as a whole)
             const int n = n0 + hil[r], iy = iy0 + hrr[r], ix = ix0 + hcc[r];
             const bool ok = wofs[r] >= 0 && n < a.N && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
             const int pix = iy * a.Win + ix;
-            voff1[r] = ok ? (hil[r] * a.C1 * HW + pix) * 4 : (int)0x80000000;   // beyond the buffer range: the load returns 0
-            voff2[r] = ok ? (hil[r] * a.C2 * HW + pix) * 4 : (int)0x80000000;
+            voff1[r] = ok ? (hil[r] * a.C1 * HW + pix) * ES : (int)0x80000000;   // beyond the buffer range: the load returns 0
+            voff2[r] = ok ? (hil[r] * a.C2 * HW + pix) * ES : (int)0x80000000;
         }
     };
-    float f[3][8];
+    unsigned f[R][8];
     auto fetch = [&](int c0) {      // channels c0 .. c0+15 of the concatenated input -> registers
         // buffer bases at the chunk's first channel of each source: the per-channel scalar offset stays small
         // whatever the plane size (4096^2 planes: 64 MB per channel)
         const int b1 = min(c0, a.C1), b2 = max(c0 - a.C1, 0);
-        const rsrc_t r1 = make_rsrc(a.x + ((long)n0 * a.C1 + b1) * HW);
-        const rsrc_t r2 = make_rsrc(a.C2 ? a.x2 + ((long)n0 * a.C2 + b2) * HW : a.x);
+        const char *x1 = reinterpret_cast<const char *>(a.x), *x2 = reinterpret_cast<const char *>(a.x2);
+        const rsrc_t r1 = make_rsrc(x1 + ((long)n0 * a.C1 + b1) * HW * ES);
+        const rsrc_t r2 = make_rsrc(a.C2 ? x2 + ((long)n0 * a.C2 + b2) * HW * ES : x1);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < R; ++r) {
             const int cg = __builtin_amdgcn_readfirstlane((tid + r * kTileThreads) / P64);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -347,22 +362,39 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
                 unsigned v = 0;
                 if (cg < 2 && ch < Cin && !(k.diag & 1)) {
                     if (ch < a.C1)
-                        v = __builtin_amdgcn_raw_buffer_load_b32(r1, voff1[r], (ch - b1) * HW * 4, 0);
+                        v = __builtin_amdgcn_raw_buffer_load_b32(r1, voff1[r], (ch - b1) * HW * ES, 0);
                     else
-                        v = __builtin_amdgcn_raw_buffer_load_b32(r2, voff2[r], (ch - a.C1 - b2) * HW * 4, 0);
+                        v = __builtin_amdgcn_raw_buffer_load_b32(r2, voff2[r], (ch - a.C1 - b2) * HW * ES, 0);
                 }
-                f[r][j] = __builtin_bit_cast(float, v);
+                f[r][j] = v;
             }
         }
     };
     auto convert_store = [&](int b) {   // registers -> 16 bit -> LDS stage b, [group][pixel][8]
         const int base = stage0 + b * stageBytes;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            V8 v;
+        for (int r = 0; r < R; ++r) {
+            if constexpr (X16) {
+                // dword j = channel j of two neighbouring pixels (low half: the even column).  Transpose to
+                // pixel-major: v_perm_b32 picks the low (high) halves of a channel pair
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(3))) u32x4 *lds_u4w;
+                u32x4 lo, hi;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (T)f[r][j];
-            if (wofs[r] >= 0) *(lds_v8w)(__SIZE_TYPE__)(unsigned)(base + wofs[r]) = v;
+                for (int j = 0; j < 4; ++j) {
+                    lo[j] = __builtin_amdgcn_perm(f[r][2 * j + 1], f[r][2 * j], 0x05040100u);
+                    hi[j] = __builtin_amdgcn_perm(f[r][2 * j + 1], f[r][2 * j], 0x07060302u);
+                }
+                if (wofs[r] >= 0) {
+                    *(lds_u4w)(__SIZE_TYPE__)(unsigned)(base + wofs[r]) = lo;
+                    *(lds_u4w)(__SIZE_TYPE__)(unsigned)(base + wofs[r] + 16) = hi;
+                }
+            } else {
+                V8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (T)__uint_as_float(f[r][j]);
+                if (wofs[r] >= 0) *(lds_v8w)(__SIZE_TYPE__)(unsigned)(base + wofs[r]) = v;
+            }
         }
     };
     const float *wslab = reinterpret_cast<const float *>(k.w16) + (long)nb * k.nchunks * (wBytes >> 2);
@@ -395,7 +427,7 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
     for (int mt = 0; mt < MT; ++mt) {
         const int p = (wave * MT + mt) * 16 + l15;
         const int il = p >> lgT, rr = (p >> a.lgTC) & TRm, c = p & TCm;
-        abase[mt] = ((il * k.inRows + rr) * k.inCols + c) * 16;
+        abase[mt] = ((il * k.inRows + rr) * k.inCols + c + k.cshift) * 16;
     }
     const int baddr0 = stage0 + inBytes + (lq * NT16 + l15) * 16;
     constexpr int bstep = 4 * NT16 * 16;
@@ -489,7 +521,6 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
                 const int co = nb * NT16 + nt * 16 + l15;
                 if (co >= a.Cout) continue;
                 const float sc = esc[nt], sh = esh[nt];
-                float *yc = a.y + co * planeY;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if (poff[mt] < 0) continue;
@@ -497,15 +528,34 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = apply_act(c[j] * sc + sh, a.act);
-                    float *q = yc + poff[mt];
-                    if (a.up2) {
-                        const float4 lo = make_float4(v[0], v[0], v[1], v[1]), hi = make_float4(v[2], v[2], v[3], v[3]);
-                        *reinterpret_cast<float4 *>(q) = lo;
-                        *reinterpret_cast<float4 *>(q + 4) = hi;
-                        *reinterpret_cast<float4 *>(q + W2) = lo;
-                        *reinterpret_cast<float4 *>(q + W2 + 4) = hi;
+                    if constexpr (Y16) {
+                        // the one rounding of a 16-bit activation tensor: here, at the store
+                        typedef T t4 __attribute__((ext_vector_type(4)));
+                        typedef T t8 __attribute__((ext_vector_type(8)));
+                        T *q = reinterpret_cast<T *>(a.y) + co * planeY + poff[mt];
+                        if (a.up2) {
+                            t8 row;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) row[2 * j] = row[2 * j + 1] = (T)v[j];
+                            *reinterpret_cast<t8 *>(q) = row;
+                            *reinterpret_cast<t8 *>(q + W2) = row;
+                        } else {
+                            t4 o;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+                            *reinterpret_cast<t4 *>(q) = o;
+                        }
                     } else {
-                        *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                        float *q = a.y + co * planeY + poff[mt];
+                        if (a.up2) {
+                            const float4 lo = make_float4(v[0], v[0], v[1], v[1]), hi = make_float4(v[2], v[2], v[3], v[3]);
+                            *reinterpret_cast<float4 *>(q) = lo;
+                            *reinterpret_cast<float4 *>(q + 4) = hi;
+                            *reinterpret_cast<float4 *>(q + W2) = lo;
+                            *reinterpret_cast<float4 *>(q + W2 + 4) = hi;
+                        } else {
+                            *reinterpret_cast<float4 *>(q) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
                     }
                 }
             }
@@ -517,70 +567,98 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
 }
 
 // =====================================================================================================================
-// conv16_head_kernel: the wide 1x1 layers (384 -> up to 384 channels: the blind-spot U-Net's output block).
-// conv16_mfma_kernel gives every 96-channel output block its own workgroup, so the 384-channel input tile is staged
-// four times (and in fp32).  Here ONE workgroup computes all output channels of 128 consecutive pixels: 8 waves =
-// 2 pixel halves x 4 output-channel quarters (64 pixels x 96 channels each, 96 accumulator registers), the input is
-// fetched once HBM -> registers (8 channels of one pixel per lane, consecutive lanes on consecutive pixels), converted
-// and written channel-innermost [8-channel group][pixel][8 x 16 bit]; the weight chunk (64 input channels x 384 outputs,
-// 48 KB as 16 bit) comes from L2 by LDS-DMA.  Two k-steps (64 channels) per barrier, double buffered.
+// conv16_head_kernel: the 1x1 layers (the per-pixel heads: 384 -> 384 -> 96 of the blind-spot U-Net, 96 -> 96 -> 96 of
+// the sigma net, and their backward-data 384 <- 384 <- 96, 96 <- 96).
+// conv16_mfma_kernel gives every 96-channel output block its own workgroup, so a 384-channel input tile is staged four
+// times (and in fp32).  Here ONE workgroup computes ALL output channels of a run of consecutive pixels: 8 waves =
+// (8 / CQ) pixel groups of 64 x CQ output-channel quarters of 96 (CQ = 4: up to 384 outputs, 128 pixels per tile;
+// CQ = 1: up to 96 outputs, 512 pixels per tile), 64 pixels x 96 channels = 96 accumulator registers per wave.  The
+// input is fetched once HBM -> registers (8 channels of one pixel — or, from a 16-bit tensor, of two pixels — per lane,
+// consecutive lanes on consecutive pixels), converted if it is fp32 and written channel-innermost
+// [8-channel group][pixel][8 x 16 bit]; the weight chunk (CK input channels x all outputs) comes from L2 by LDS-DMA.
+// CK / 32 k-steps per barrier, double buffered.
 // =====================================================================================================================
 struct Head16Args {
-    const float *x;      // [N][Cin][HW]
-    const void *w16;     // [chunks][8 groups][384][8]  (weight_transform16_kernel with CK = 64, G4 = 8, NT16 = 384)
+    const void *x;       // [N][Cin][HW], fp32 or T
+    const void *w16;     // [chunks][CK / 8 groups][96 CQ][8]  (wprep_16 with G4 = CK / 8, NT16 = 96 CQ)
     const float *bias, *scale, *shift;
-    float *y;            // [N][Cout][HW]
+    void *y;             // [N][Cout][HW], fp32 or T
     int N, Cin, Cout, HW, act, nchunks, tilesPerImage;
 };
 
-constexpr int kHeadCK = 64, kHeadPx = 128, kHeadCoutP = 384;
-
-template <typename T>
+template <typename T, int CQ, int CK, bool X16, bool Y16>
 __global__ __launch_bounds__(512) void conv16_head_kernel(const Head16Args a) {
     using V8 = typename Op16<T>::v8;
     typedef const __attribute__((address_space(3))) V8 *lds_v8p;
     typedef __attribute__((address_space(3))) V8 *lds_v8w;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int inBytes = 8 * kHeadPx * 16, wBytes = 8 * kHeadCoutP * 16, stageBytes = inBytes + wBytes;
+    constexpr int GC = CK / 8, PXT = 64 * (8 / CQ), COUTP = 96 * CQ, NKS = CK / 32;
+    constexpr int inBytes = GC * PXT * 16, wBytes = GC * COUTP * 16, stageBytes = inBytes + wBytes;
+    constexpr int ES = X16 ? 2 : 4;
+    constexpr int IPG = X16 ? PXT / 2 : PXT;                    // fetch items per channel group (pixel pairs / pixels)
+    constexpr int ITEMS = GC * IPG, R = (ITEMS + 511) / 512;
     const int lds0 = lds_addr(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
-    const int pg = wave >> 2, cq = wave & 3;                    // pixel half, output-channel quarter
+    const int pg = wave / CQ, cq = wave - pg * CQ;              // pixel group of 64, output-channel quarter
     const int tile = blockIdx.x;
-    const int n = tile / a.tilesPerImage, p0 = (tile - n * a.tilesPerImage) * kHeadPx;
-    // fetch items: thread -> (channel group cg = 0..7 of the chunk, pixel): two items per thread (cg, cg + 4)
-    const int fpx = tid & (kHeadPx - 1), fcg = tid >> 7;        // fcg 0..3 (wave-uniform), items fcg and fcg + 4
-    const bool pok = p0 + fpx < a.HW;
-    const int voff = pok ? (p0 + fpx) * 4 : (int)0x80000000;
-    float f[2][8];
+    const int n = tile / a.tilesPerImage, p0 = (tile - n * a.tilesPerImage) * PXT;
+    // fetch item i = tid + 512 r -> (channel group i / IPG (wave-uniform: IPG is a multiple of 64), pixel or pixel pair)
+    int fgrp[R], fpx[R], voff[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = tid + 512 * r;
+        fgrp[r] = __builtin_amdgcn_readfirstlane(i / IPG);
+        const int ip = i - fgrp[r] * IPG;
+        fpx[r] = X16 ? 2 * ip : ip;
+        const bool ok = i < ITEMS && p0 + fpx[r] < a.HW;         // HW % 4 == 0: a pair is inside or outside as a whole
+        voff[r] = ok ? (p0 + fpx[r]) * ES : (int)0x80000000;
+        if (i >= ITEMS) fgrp[r] = -1;
+    }
+    unsigned f[R][8];
     auto fetch = [&](int chunk) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int r = 0; r < R; ++r) {
             // buffer based at the 8-channel group (wave-uniform): the scalar channel offset stays below 2^31 on 4096^2 planes
-            const int ch0 = chunk * kHeadCK + (fcg + 4 * h) * 8;
-            const rsrc_t rx = make_rsrc(a.x + ((long)n * a.Cin + ch0) * a.HW);
+            const int ch0 = chunk * CK + fgrp[r] * 8;
+            const rsrc_t rx = make_rsrc(reinterpret_cast<const char *>(a.x) + ((long)n * a.Cin + ch0) * a.HW * ES);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 unsigned v = 0;
-                if (ch0 + j < a.Cin) v = __builtin_amdgcn_raw_buffer_load_b32(rx, voff, j * a.HW * 4, 0);
-                f[h][j] = __builtin_bit_cast(float, v);
+                if (fgrp[r] >= 0 && ch0 + j < a.Cin) v = __builtin_amdgcn_raw_buffer_load_b32(rx, voff[r], j * a.HW * ES, 0);
+                f[r][j] = v;
             }
         }
     };
     auto convert_store = [&](int b) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            V8 v;
+        for (int r = 0; r < R; ++r) {
+            if (fgrp[r] < 0) continue;
+            const int dst = lds0 + b * stageBytes + (fgrp[r] * PXT + fpx[r]) * 16;
+            if constexpr (X16) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(3))) u32x4 *lds_u4w;
+                u32x4 lo, hi;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (T)f[h][j];
-            *(lds_v8w)(__SIZE_TYPE__)(unsigned)(lds0 + b * stageBytes + ((fcg + 4 * h) * kHeadPx + fpx) * 16) = v;
+                for (int j = 0; j < 4; ++j) {
+                    lo[j] = __builtin_amdgcn_perm(f[r][2 * j + 1], f[r][2 * j], 0x05040100u);
+                    hi[j] = __builtin_amdgcn_perm(f[r][2 * j + 1], f[r][2 * j], 0x07060302u);
+                }
+                *(lds_u4w)(__SIZE_TYPE__)(unsigned)dst = lo;
+                *(lds_u4w)(__SIZE_TYPE__)(unsigned)(dst + 16) = hi;
+            } else {
+                V8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (T)__uint_as_float(f[r][j]);
+                *(lds_v8w)(__SIZE_TYPE__)(unsigned)dst = v;
+            }
         }
     };
     auto weights = [&](int chunk, int b) {
         const rsrc_t wr = make_rsrc(reinterpret_cast<const float *>(a.w16) + (long)chunk * (wBytes >> 2));
         float *w_lds = smem + ((b * stageBytes + inBytes) >> 2);
-        constexpr int total16 = wBytes >> 4;                    // 3072 pieces of 16 bytes = 48 wave instructions
+        constexpr int total16 = wBytes >> 4;                    // pieces of 16 bytes: a multiple of 64
         for (int gi = wave; gi * 64 < total16; gi += 8) bdma16(wr, lane * 16, gi * 1024, w_lds + gi * 256);
     };
     f32x4 acc[4][6];
@@ -589,8 +667,8 @@ __global__ __launch_bounds__(512) void conv16_head_kernel(const Head16Args a) {
 #pragma unroll
         for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     // A: [group][pixel][8]: lane (pixel l15 of tile mt, quarter lq -> group 4 ks + lq);  B: [group][cout][8]
-    const int abase = lds0 + (lq * kHeadPx + pg * 64 + l15) * 16;
-    const int bbase = lds0 + inBytes + (lq * kHeadCoutP + cq * 96 + l15) * 16;
+    const int abase = lds0 + (lq * PXT + pg * 64 + l15) * 16;
+    const int bbase = lds0 + inBytes + (lq * COUTP + cq * 96 + l15) * 16;
     fetch(0);
     weights(0, 0);
     convert_store(0);
@@ -603,14 +681,14 @@ __global__ __launch_bounds__(512) void conv16_head_kernel(const Head16Args a) {
         }
         const int sb = (c & 1) * stageBytes;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
             V8 av[4], bv[6];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                av[mt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(abase + sb + ks * 4 * kHeadPx * 16 + mt * 256);
+                av[mt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(abase + sb + ks * 4 * PXT * 16 + mt * 256);
 #pragma unroll
             for (int nt = 0; nt < 6; ++nt)
-                bv[nt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(bbase + sb + ks * 4 * kHeadCoutP * 16 + nt * 256);
+                bv[nt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(bbase + sb + ks * 4 * COUTP * 16 + nt * 256);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -640,13 +718,23 @@ __global__ __launch_bounds__(512) void conv16_head_kernel(const Head16Args a) {
         const int co = cq * 96 + nt * 16 + l15;
         if (co >= a.Cout) continue;
         const float sc = esc[nt], sh = esh[nt];
-        float *yc = a.y + ((long)n * a.Cout + co) * a.HW + p0 + pg * 64 + lq * 4;
+        const long e0 = ((long)n * a.Cout + co) * a.HW + p0 + pg * 64 + lq * 4;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             if (p0 + pg * 64 + mt * 16 + lq * 4 >= a.HW) continue;      // HW % 4 == 0: a quad is all in or all out
             const f32x4 c4 = acc[mt][nt];
-            *reinterpret_cast<float4 *>(yc + mt * 16) = make_float4(apply_act(c4[0] * sc + sh, a.act), apply_act(c4[1] * sc + sh, a.act),
-                                                                    apply_act(c4[2] * sc + sh, a.act), apply_act(c4[3] * sc + sh, a.act));
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = apply_act(c4[j] * sc + sh, a.act);
+            if constexpr (Y16) {
+                typedef T t4 __attribute__((ext_vector_type(4)));
+                t4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+                *reinterpret_cast<t4 *>(reinterpret_cast<T *>(a.y) + e0 + mt * 16) = o;
+            } else {
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(a.y) + e0 + mt * 16) = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
     }
 }
@@ -747,11 +835,11 @@ std::atomic<long> g_conv16_launches{0};
 // ---- 3x3 layers: conv16_tile_kernel -----------------------------------------------------------------------------
 struct PlanT {
     int NT, lgTC, lgTR, tilesX, tilesY, imgGroups, nblkN, NI;
-    int G4, nchunks, PX, PXP, inRows, inCols;
+    int G4, nchunks, PX, PXP, inRows, inCols, cshift;
     size_t ldsBytes, wsBytes;
 };
 
-bool plan_tile(int Nimg, int Ck, int Nn, int Ho, int Wo, PlanT *p) {
+bool plan_tile(int Nimg, int Ck, int Nn, int Ho, int Wo, int x16, int padL, PlanT *p) {
     using sprk::cdiv;
     if (Nn < 33 || (long)Ho * Wo < 256 || Wo % 4 != 0) return false;
     const int ntile = cdiv(Nn, 16);
@@ -765,7 +853,10 @@ bool plan_tile(int Nimg, int Ck, int Nn, int Ho, int Wo, PlanT *p) {
     p->imgGroups = cdiv(Nimg, NI);
     p->nblkN = cdiv(ntile, p->NT);
     if ((long)p->imgGroups * p->tilesX * p->tilesY * p->nblkN < 128) return false;   // too few workgroups: fp32 path
-    p->inRows = TR + 2; p->inCols = TC + 2;
+    // 16-bit input: the halo columns ix0 .. ix0 + TC + 1 (ix0 = ox0 - padL) sit on a grid of aligned pixel pairs that
+    // starts at the even column ix0 - cshift
+    p->cshift = x16 ? (padL & 1) : 0;
+    p->inRows = TR + 2; p->inCols = x16 ? sprk::roundup(TC + 2 + p->cshift, 2) : TC + 2;
     p->PX = NI * p->inRows * p->inCols;
     if (p->PX > 768) return false;
     p->PXP = sprk::roundup(p->PX, 16);
@@ -776,7 +867,7 @@ bool plan_tile(int Nimg, int Ck, int Nn, int Ho, int Wo, PlanT *p) {
     return true;
 }
 
-template <typename T>
+template <typename T, bool X16, bool Y16>
 int launch_tile(const Tile16Args &k, const PlanT &p, hipStream_t s) {
     // persistent workgroups: one per CU (8 waves at 159-225 VGPRs fill it), shared among the output-channel blocks
     const int ntiles = p.imgGroups * p.tilesX * p.tilesY;
@@ -792,12 +883,28 @@ int launch_tile(const Tile16Args &k, const PlanT &p, hipStream_t s) {
         hipLaunchKernelGGL(kernel, grid, dim3(kTileThreads), p.ldsBytes, s, k);
         return (int)SPRK_OK;
     };
-    return p.NT == 3 ? go(conv16_tile_kernel<T, 3>) : go(conv16_tile_kernel<T, 6>);
+    return p.NT == 3 ? go(conv16_tile_kernel<T, 3, X16, Y16>) : go(conv16_tile_kernel<T, 6, X16, Y16>);
+}
+template <typename T>
+int launch_tile_io(const Tile16Args &k, const PlanT &p, int x16, int y16, hipStream_t s) {
+    if (x16) return y16 ? launch_tile<T, true, true>(k, p, s) : launch_tile<T, true, false>(k, p, s);
+    return y16 ? launch_tile<T, false, true>(k, p, s) : launch_tile<T, false, false>(k, p, s);
 }
 
 }  // namespace
 
 namespace sprk {
+
+// head kernel shape of a call: CQ = 4 (97..384 outputs) or 1 (<= 96); CK = 64 where the input channels allow, else 32
+static void head_shape(const Conv16Call &c, int *cq, int *ck) {
+    *cq = c.Cout > 96 ? 4 : 1;
+    *ck = (*cq == 4 && c.C1 % 64 == 0) ? 64 : 32;
+}
+static size_t head_ws_bytes(const Conv16Call &c) {
+    int cq, ck;
+    head_shape(c, &cq, &ck);
+    return (size_t)(c.C1 / ck) * (ck / 8) * 96 * cq * 16;
+}
 
 // which 16-bit kernel (if any) takes this call: 2 = conv16_tile_kernel (3x3), 1 = conv16_mfma_kernel (1x1), 0 = none
 static int plan_of(const Conv16Call &c, Plan16 *p, PlanT *pt) {
@@ -809,21 +916,23 @@ static int plan_of(const Conv16Call &c, Plan16 *p, PlanT *pt) {
     if (c.Hout != c.Hin || c.Wout != c.Win) return 0;                 // same-size layers (U-Net body)
     if (c.padL < 0 || c.padL > 4 || c.padT < 0) return 0;
     if (c.KH == 1 && c.KW == 1 && !c.C2 && !c.up2 && c.padT == 0 && c.padL == 0) {
-        // conv16_head_kernel: 193..384 output channels, input channels a multiple of 64, planes of 4k pixels
+        // conv16_head_kernel: 33..384 output channels, input channels a multiple of 32, planes of 4k pixels
         static const int head_on = getenv("SPRK_CONV16_HEAD") ? atoi(getenv("SPRK_CONV16_HEAD")) : 1;   // debug
         const long HW = (long)c.Hin * c.Win;
-        if (head_on && c.Cout > 192 && c.Cout <= kHeadCoutP && c.C1 % kHeadCK == 0 && HW % 4 == 0 &&
-            8 * HW * 4 < (1L << 31) && (long)c.N * cdiv(HW, kHeadPx) >= 256)
+        const int pxt = c.Cout > 96 ? 128 : 512;
+        if (head_on && c.Cout >= 33 && c.Cout <= 384 && c.C1 % 32 == 0 && HW % 4 == 0 && 8 * HW * 4 < (1L << 31) &&
+            (long)c.N * cdiv(HW, pxt) >= 128)
             return 3;
     }
     if (c.KH == 3 && c.KW == 3) {
         static const int tile_on = getenv("SPRK_CONV16_TILE") ? atoi(getenv("SPRK_CONV16_TILE")) : 1;   // debug
-        if (tile_on && plan_tile(c.N, c.C1 + c.C2, c.Cout, c.Hout, c.Wout, pt)) {
+        if (tile_on && plan_tile(c.N, c.C1 + c.C2, c.Cout, c.Hout, c.Wout, c.x16, c.padL, pt)) {
             // 32-bit byte offsets: an image group's span and 16 channel planes
             const long HW = (long)c.Hin * c.Win, cmax = std::max(c.C1, c.C2);
             if (((pt->NI - 1) * cmax + 1) * HW * 4 < (1L << 31) && 16 * HW * 4 < (1L << 31)) return 2;
         }
     }
+    if (c.x16 || c.y16) return 0;       // 16-bit activation storage: conv16_tile_kernel / conv16_head_kernel only
     // Where the fp32 Winograd kernel is the faster one (measured on MI355X, scratch/convbench.py): on the wide 3x3
     // layers at 64x64 and up the 256-pixel-tile kernel is bound by moving fp32 tiles through LDS-DMA (96->96 at
     // 128x64^2: 455 us fp32 Winograd, 570 us here).  Without SPRK_DT_FORCE those layers stay fp32.
@@ -836,23 +945,24 @@ static int plan_of(const Conv16Call &c, Plan16 *p, PlanT *pt) {
     return 1;
 }
 
-bool conv16_eligible(const Conv16Call &c) {
+bool conv16_eligible(const Conv16Call &c) { return conv16_kind(c) != 0; }
+int conv16_kind(const Conv16Call &c) {
     Plan16 p;
     PlanT pt;
-    return plan_of(c, &p, &pt) != 0;
+    return plan_of(c, &p, &pt);
 }
 
 size_t conv16_ws_bytes(const Conv16Call &c) {
     Plan16 p;
     PlanT pt;
     const int which = plan_of(c, &p, &pt);
-    if (which == 3) return (size_t)(c.C1 / kHeadCK) * 8 * kHeadCoutP * 16 + 512;
+    if (which == 3) return head_ws_bytes(c) + 512;
     return which == 2 ? pt.wsBytes + 512 : which == 1 ? p.wsBytes + 512 : 0;
 }
 
 long conv16_launches() { return g_conv16_launches.load(); }
 
-static int run_tile(const Conv16Call &c, const PlanT &p, const float *x, const float *x2, const float *w, float *y,
+static int run_tile(const Conv16Call &c, const PlanT &p, const void *x, const void *x2, const float *w, void *y,
                     void *ws, size_t ws_bytes, hipStream_t s) {
     if (ws_bytes < p.wsBytes || !ws) {
         set_error("conv16: workspace too small (%zu < %zu)", ws_bytes, p.wsBytes);
@@ -869,7 +979,8 @@ static int run_tile(const Conv16Call &c, const PlanT &p, const float *x, const f
     if (int rc = transform16(c, w, ws, total, wCout, wCin, 9, kTileCK, p.G4, p.NT * 16, p.nblkN, p.nchunks, s)) return rc;
     Tile16Args k{};
     ConvArgs &a = k.c;
-    a.x = x; a.x2 = x2; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift; a.res = nullptr; a.y = y;
+    a.x = (const float *)x; a.x2 = (const float *)x2; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift; a.res = nullptr;
+    a.y = (float *)y;
     a.N = c.N; a.C1 = c.C1; a.C2 = c.C2; a.Hin = c.Hin; a.Win = c.Win; a.H1 = c.Hin; a.W1 = c.Win;
     a.Cout = c.Cout; a.Hout = c.Hout; a.Wout = c.Wout; a.KH = 3; a.KW = 3; a.stride = 1; a.dil = 1;
     a.padT = c.padT; a.padL = c.padL; a.act = c.act;
@@ -881,23 +992,43 @@ static int run_tile(const Conv16Call &c, const PlanT &p, const float *x, const f
     const int ckeLast = Cin - (p.nchunks - 1) * kTileCK;
     k.c8Last = cdiv(ckeLast, 8);
     k.ngLast = 9 * k.c8Last;
-    k.PX = p.PX; k.PXP = p.PXP; k.inRows = p.inRows; k.inCols = p.inCols;
+    k.PX = p.PX; k.PXP = p.PXP; k.inRows = p.inRows; k.inCols = p.inCols; k.cshift = p.cshift;
     k.ntiles = p.imgGroups * p.tilesX * p.tilesY;
     static const int diag = sprk::diag_env("SPRK_C16_DIAG");
     k.diag = diag;
     prof_begin(c.kclass, c.flops, s);
-    prof_bytes(4.0 * c.N * ((double)(c.C1 + c.C2) * c.Hin * c.Win + (double)c.Cout * c.Hout * c.Wout * (c.up2 ? 4 : 1)));
-    const int rc = dt == SPRK_DT_BF16 ? launch_tile<__bf16>(k, p, s) : launch_tile<_Float16>(k, p, s);
+    prof_bytes(c.N * ((c.x16 ? 2.0 : 4.0) * (c.C1 + c.C2) * c.Hin * c.Win +
+                      (c.y16 ? 2.0 : 4.0) * c.Cout * c.Hout * c.Wout * (c.up2 ? 4 : 1)));
+    const int rc = dt == SPRK_DT_BF16 ? launch_tile_io<__bf16>(k, p, c.x16, c.y16, s)
+                                      : launch_tile_io<_Float16>(k, p, c.x16, c.y16, s);
     if (rc) return rc;
     prof_end(c.kclass, s);
     g_conv16_launches.fetch_add(1, std::memory_order_relaxed);
     return check_launch("conv16_tile");
 }
 
-static int run_head(const Conv16Call &c, const float *x, const float *w, float *y, void *ws, size_t ws_bytes,
+template <typename T, int CQ, int CK>
+static int launch_head(const Head16Args &a, int x16, int y16, hipStream_t s) {
+    constexpr size_t lds = 2 * (size_t)((CK / 8) * 64 * (8 / CQ) * 16 + (CK / 8) * 96 * CQ * 16);
+    auto go = [&](auto kernel) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            set_error("conv16: cannot reserve %zu bytes of LDS", lds);
+            return (int)SPRK_ELAUNCH;
+        }
+        hipLaunchKernelGGL(kernel, dim3(a.N * a.tilesPerImage), dim3(512), lds, s, a);
+        return (int)SPRK_OK;
+    };
+    if (x16) return y16 ? go(conv16_head_kernel<T, CQ, CK, true, true>) : go(conv16_head_kernel<T, CQ, CK, true, false>);
+    return y16 ? go(conv16_head_kernel<T, CQ, CK, false, true>) : go(conv16_head_kernel<T, CQ, CK, false, false>);
+}
+
+static int run_head(const Conv16Call &c, const void *x, const float *w, void *y, void *ws, size_t ws_bytes,
                     hipStream_t s) {
-    const int nchunks = c.C1 / kHeadCK;
-    const size_t need = (size_t)nchunks * 8 * kHeadCoutP * 16;
+    int cq, ck;
+    head_shape(c, &cq, &ck);
+    const int nchunks = c.C1 / ck, gc = ck / 8, coutp = 96 * cq, pxt = 64 * (8 / cq);
+    const size_t need = head_ws_bytes(c);
     if (ws_bytes < need || !ws) {
         set_error("conv16: workspace too small (%zu < %zu)", ws_bytes, need);
         return SPRK_EWORKSPACE;
@@ -907,43 +1038,40 @@ static int run_head(const Conv16Call &c, const float *x, const float *w, float *
         return SPRK_EINVAL;
     }
     const int dt = c.dtype & SPRK_DT_MASK;
-    const long total = (long)nchunks * 8 * kHeadCoutP * 8;
+    const long total = (long)nchunks * gc * coutp * 8;
     const int wCout = c.mode == 0 ? c.Cout : c.C1, wCin = c.mode == 0 ? c.C1 : c.Cout;
-    if (int rc = transform16(c, w, ws, total, wCout, wCin, 1, kHeadCK, 8, kHeadCoutP, 1, nchunks, s)) return rc;
+    if (int rc = transform16(c, w, ws, total, wCout, wCin, 1, ck, gc, coutp, 1, nchunks, s)) return rc;
     Head16Args a{};
     a.x = x; a.w16 = ws; a.bias = c.bias; a.scale = c.scale; a.shift = c.shift; a.y = y;
     a.N = c.N; a.Cin = c.C1; a.Cout = c.Cout; a.HW = c.Hin * c.Win; a.act = c.act; a.nchunks = nchunks;
-    a.tilesPerImage = cdiv(a.HW, kHeadPx);
-    const size_t lds = 2 * (size_t)(8 * kHeadPx * 16 + 8 * kHeadCoutP * 16);
-    auto go = [&](auto kernel) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            set_error("conv16: cannot reserve %zu bytes of LDS", lds);
-            return (int)SPRK_ELAUNCH;
-        }
-        hipLaunchKernelGGL(kernel, dim3(c.N * a.tilesPerImage), dim3(512), lds, s, a);
-        return (int)SPRK_OK;
-    };
+    a.tilesPerImage = cdiv(a.HW, pxt);
     prof_begin(c.kclass, c.flops, s);
-    prof_bytes(4.0 * c.N * ((double)(c.C1 + c.C2) * c.Hin * c.Win + (double)c.Cout * c.Hout * c.Wout * (c.up2 ? 4 : 1)));
-    const int rc = dt == SPRK_DT_BF16 ? go(conv16_head_kernel<__bf16>) : go(conv16_head_kernel<_Float16>);
+    prof_bytes(c.N * ((c.x16 ? 2.0 : 4.0) * c.C1 * c.Hin * c.Win + (c.y16 ? 2.0 : 4.0) * c.Cout * c.Hout * c.Wout));
+    auto pick = [&](auto tag) {
+        using T = decltype(tag);
+        if (cq == 4) return ck == 64 ? launch_head<T, 4, 64>(a, c.x16, c.y16, s) : launch_head<T, 4, 32>(a, c.x16, c.y16, s);
+        return launch_head<T, 1, 32>(a, c.x16, c.y16, s);
+    };
+    const int rc = dt == SPRK_DT_BF16 ? pick(__bf16{}) : pick(_Float16{});
     if (rc) return rc;
     prof_end(c.kclass, s);
     g_conv16_launches.fetch_add(1, std::memory_order_relaxed);
     return check_launch("conv16_head");
 }
 
-int conv16_run(const Conv16Call &c, const float *x, const float *x2, const float *w, float *y, void *ws, size_t ws_bytes,
+int conv16_run(const Conv16Call &c, const void *xv, const void *x2v, const float *w, void *yv, void *ws, size_t ws_bytes,
                hipStream_t s) {
     Plan16 p;
     PlanT pt;
     const int which = plan_of(c, &p, &pt);
-    if (which == 3) return run_head(c, x, w, y, ws, ws_bytes, s);
-    if (which == 2) return run_tile(c, pt, x, x2, w, y, ws, ws_bytes, s);
+    if (which == 3) return run_head(c, xv, w, yv, ws, ws_bytes, s);
+    if (which == 2) return run_tile(c, pt, xv, x2v, w, yv, ws, ws_bytes, s);
     if (which == 0) {
-        set_error("conv16: geometry not eligible");
+        set_error("conv16: geometry not eligible%s", (c.x16 || c.y16) ? " for 16-bit activation storage" : "");
         return SPRK_EINVAL;
     }
+    const float *x = (const float *)xv, *x2 = (const float *)x2v;
+    float *y = (float *)yv;
     if (ws_bytes < p.wsBytes || !ws) {
         set_error("conv16: workspace too small (%zu < %zu)", ws_bytes, p.wsBytes);
         return SPRK_EWORKSPACE;

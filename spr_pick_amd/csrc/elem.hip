@@ -2,6 +2,7 @@
 // Every kernel reads each input element once and writes each output element once
 // (coalesced along x); none of them is reshaped into a GEMM.
 #include "common.h"
+#include "io_dev.h"
 
 #include <algorithm>
 
@@ -9,12 +10,16 @@ namespace {
 
 // ---- Shift2d((shift,0)) + MaxPool2d(2) -------------------------------------------------------
 // xs = x shifted down by `shift` rows (zeros on top, last rows dropped); y = 2x2/2 max of xs.
-__device__ __forceinline__ float shifted(const float *p, int u, int v, int W, int shift) {
+// (TX / TY / TG ...: element types of the tensors, fp32 or the 16-bit storage type: io_dev.h.  max commutes with the
+// monotone rounding of a 16-bit tensor, so pooling 16-bit values equals rounding the pooled fp32 values.)
+template <typename TX>
+__device__ __forceinline__ float shifted(const TX *p, int u, int v, int W, int shift) {
     const int r = u - shift;
-    return r >= 0 ? p[(long)r * W + v] : 0.f;
+    return r >= 0 ? IO<TX>::ld(p + (long)r * W + v) : 0.f;
 }
 
-__global__ void shift_maxpool2_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int NC, int H, int W,
+template <typename TX, typename TY>
+__global__ void shift_maxpool2_fwd_kernel(const TX *__restrict__ x, TY *__restrict__ y, int NC, int H, int W,
                                           int shift) {
     const int Ho = H >> 1, Wo = W >> 1;
     const long total = (long)NC * Ho * Wo;
@@ -23,7 +28,7 @@ __global__ void shift_maxpool2_fwd_kernel(const float *__restrict__ x, float *__
         const int j = (int)(t % Wo); t /= Wo;
         const int i = (int)(t % Ho);
         const long nc = t / Ho;
-        const float *p = x + nc * H * W;
+        const TX *p = x + nc * H * W;
         float m = shifted(p, 2 * i, 2 * j, W, shift);
         float v = shifted(p, 2 * i, 2 * j + 1, W, shift);
         if (v > m || v != v) m = v;
@@ -31,7 +36,7 @@ __global__ void shift_maxpool2_fwd_kernel(const float *__restrict__ x, float *__
         if (v > m || v != v) m = v;
         v = shifted(p, 2 * i + 1, 2 * j + 1, W, shift);
         if (v > m || v != v) m = v;
-        y[e] = m;
+        IO<TY>::st(y + e, m);
     }
 }
 
@@ -45,35 +50,37 @@ __device__ __forceinline__ float max4_first(float a, float b, float c, float d) 
     return m;
 }
 
-__global__ __launch_bounds__(256) void shift_maxpool2_fwd_v4_kernel(const float *__restrict__ x, float *__restrict__ y,
+template <typename TX, typename TY>
+__global__ __launch_bounds__(256) void shift_maxpool2_fwd_v4_kernel(const TX *__restrict__ x, TY *__restrict__ y,
                                                                     int NC, int H, int W, int shift) {
     const int Ho = H >> 1, Wo4 = W >> 3;
     const int per = Ho * Wo4;
     for (int nc = blockIdx.y; nc < NC; nc += gridDim.y) {
-        const float *p = x + (long)nc * H * W;
-        float *q = y + (long)nc * Ho * (W >> 1);
+        const TX *p = x + (long)nc * H * W;
+        TY *q = y + (long)nc * Ho * (W >> 1);
         for (int t = blockIdx.x * 256 + threadIdx.x; t < per; t += gridDim.x * 256) {
             const int i = t / Wo4, j4 = t - i * Wo4;
             const int ra = 2 * i - shift, rb = ra + 1;
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 a0 = ra >= 0 ? *reinterpret_cast<const float4 *>(p + (long)ra * W + 8 * j4) : z;
-            const float4 a1 = ra >= 0 ? *reinterpret_cast<const float4 *>(p + (long)ra * W + 8 * j4 + 4) : z;
-            const float4 b0 = rb >= 0 ? *reinterpret_cast<const float4 *>(p + (long)rb * W + 8 * j4) : z;
-            const float4 b1 = rb >= 0 ? *reinterpret_cast<const float4 *>(p + (long)rb * W + 8 * j4 + 4) : z;
+            const float4 a0 = ra >= 0 ? IO<TX>::ld4(p + (long)ra * W + 8 * j4) : z;
+            const float4 a1 = ra >= 0 ? IO<TX>::ld4(p + (long)ra * W + 8 * j4 + 4) : z;
+            const float4 b0 = rb >= 0 ? IO<TX>::ld4(p + (long)rb * W + 8 * j4) : z;
+            const float4 b1 = rb >= 0 ? IO<TX>::ld4(p + (long)rb * W + 8 * j4 + 4) : z;
             float4 o;
             o.x = max4_first(a0.x, a0.y, b0.x, b0.y);
             o.y = max4_first(a0.z, a0.w, b0.z, b0.w);
             o.z = max4_first(a1.x, a1.y, b1.x, b1.y);
             o.w = max4_first(a1.z, a1.w, b1.z, b1.w);
-            *reinterpret_cast<float4 *>(q + (long)i * (W >> 1) + 4 * j4) = o;
+            IO<TY>::st4(q + (long)i * (W >> 1) + 4 * j4, o);
         }
     }
 }
 
 // one thread per x element: it receives the window's gradient iff it is the FIRST maximum of
 // its window in row-major order (torch's max_pool2d backward rule).
-__global__ void shift_maxpool2_bwd_kernel(const float *__restrict__ gy, const float *__restrict__ x,
-                                          float *__restrict__ gx, int NC, int H, int W, int shift, int act) {
+template <typename TG, typename TX, typename TO>
+__global__ void shift_maxpool2_bwd_kernel(const TG *__restrict__ gy, const TX *__restrict__ x,
+                                          TO *__restrict__ gx, int NC, int H, int W, int shift, int act) {
     const int Ho = H >> 1, Wo = W >> 1;
     const long total = (long)NC * H * W;
     const float neg = act == SPRK_ACT_LEAKY ? 0.1f : 0.f;
@@ -86,7 +93,7 @@ __global__ void shift_maxpool2_bwd_kernel(const float *__restrict__ gy, const fl
         float g = 0.f;
         if (u < 2 * Ho && v0 < 2 * Wo) {
             const int i = u >> 1, j = v0 >> 1;
-            const float *p = x + nc * H * W;
+            const TX *p = x + nc * H * W;
             int best = 0;
             float m = shifted(p, 2 * i, 2 * j, W, shift);
 #pragma unroll
@@ -98,10 +105,10 @@ __global__ void shift_maxpool2_bwd_kernel(const float *__restrict__ gy, const fl
                 }
             }
             const int mine = ((u & 1) << 1) | (v0 & 1);
-            if (best == mine) g = gy[(nc * Ho + i) * Wo + j];
+            if (best == mine) g = IO<TG>::ld(gy + (nc * Ho + i) * Wo + j);
         }
-        if (act != SPRK_ACT_NONE && !(x[e] > 0.f)) g *= neg;
-        gx[e] = g;
+        if (act != SPRK_ACT_NONE && !(IO<TX>::ld(x + e) > 0.f)) g *= neg;
+        IO<TO>::st(gx + e, g);
     }
 }
 
@@ -117,14 +124,15 @@ __device__ __forceinline__ int first_max4(float a, float b, float c, float d) {
     return best;
 }
 
-__global__ __launch_bounds__(256) void shift_maxpool2_bwd_v4_kernel(const float *__restrict__ gy,
-                                                                    const float *__restrict__ x, float *__restrict__ gx,
+template <typename TG, typename TX, typename TO>
+__global__ __launch_bounds__(256) void shift_maxpool2_bwd_v4_kernel(const TG *__restrict__ gy,
+                                                                    const TX *__restrict__ x, TO *__restrict__ gx,
                                                                     int NC, int H, int W, int shift, int act) {
     const float neg = act == SPRK_ACT_LEAKY ? 0.1f : 0.f;
     const int Ho = H >> 1, Wo = W >> 1, W4 = W >> 2;
     const int per = H * W4;
     for (int nc = blockIdx.y; nc < NC; nc += gridDim.y) {
-        const float *p = x + (long)nc * H * W;
+        const TX *p = x + (long)nc * H * W;
         for (int t = blockIdx.x * 256 + threadIdx.x; t < per; t += gridDim.x * 256) {
             const int r0 = t / W4, q = t - r0 * W4;
             const int u = r0 + shift;               // row in the shifted image
@@ -132,9 +140,9 @@ __global__ __launch_bounds__(256) void shift_maxpool2_bwd_v4_kernel(const float 
             if (u < 2 * Ho) {
                 const int i = u >> 1, ra = (u & ~1) - shift, rb = ra + 1;   // x rows of the window (ra < 0: zeros)
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 A = ra >= 0 ? *reinterpret_cast<const float4 *>(p + (long)ra * W + 4 * q) : z;
-                const float4 B = rb >= 0 ? *reinterpret_cast<const float4 *>(p + (long)rb * W + 4 * q) : z;
-                const float2 g = *reinterpret_cast<const float2 *>(gy + ((long)nc * Ho + i) * Wo + 2 * q);
+                const float4 A = ra >= 0 ? IO<TX>::ld4(p + (long)ra * W + 4 * q) : z;
+                const float4 B = rb >= 0 ? IO<TX>::ld4(p + (long)rb * W + 4 * q) : z;
+                const float2 g = IO<TG>::ld2(gy + ((long)nc * Ho + i) * Wo + 2 * q);
                 const int b0 = first_max4(A.x, A.y, B.x, B.y), b1 = first_max4(A.z, A.w, B.z, B.w);
                 const int k0 = (u & 1) << 1;        // window positions of this thread's row: k0, k0 + 1
                 out.x = b0 == k0 ? g.x : 0.f;
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(256) void shift_maxpool2_bwd_v4_kernel(const float 
                     out.w *= X.w > 0.f ? 1.f : neg;
                 }
             }
-            *reinterpret_cast<float4 *>(gx + (long)nc * H * W + (long)r0 * W + 4 * q) = out;
+            IO<TO>::st4(gx + (long)nc * H * W + (long)r0 * W + 4 * q, out);
         }
     }
 }
@@ -212,8 +220,8 @@ __global__ void rot4_stack_bwd_kernel(const float *__restrict__ gy, float *__res
 // P % 32 == 0 anyway).  grid: (tiles per plane, planes), block 32x8.
 //   FWD:  out (i,j) of plane (b, k*C+c)  <- shifted source (u,v) = rot_src(a_k; i,j), value d[u-1][v] (0 if u == 0)
 //   BWD:  out (s,v) of plane (k*B+b, c)  <- gf (i,j) = rot_dst(a_k; s+1, v)                 (0 if s == P-1)
-template <bool FWD>
-__global__ __launch_bounds__(256) void unrot4_tiled_kernel(const float *__restrict__ in, float *__restrict__ out,
+template <bool FWD, typename TI, typename TO>
+__global__ __launch_bounds__(256) void unrot4_tiled_kernel(const TI *__restrict__ in, TO *__restrict__ out,
                                                            int B, int C, int P) {
     __shared__ float tile[32][33];
     const int tilesPer = P >> 5;
@@ -233,8 +241,8 @@ __global__ __launch_bounds__(256) void unrot4_tiled_kernel(const float *__restri
     }
     const int rot = (4 - k) & 3;
     const long plane = (long)P * P;
-    const float *src = in + (FWD ? (((long)k * B + b) * C + c) : (((long)b * 4 + k) * C + c)) * plane;
-    float *dst = out + (long)pl * plane;
+    const TI *src = in + (FWD ? (((long)k * B + b) * C + c) : (((long)b * 4 + k) * C + c)) * plane;
+    TO *dst = out + (long)pl * plane;
     const int o0 = ti << 5, o1 = tj << 5;  // output tile origin (row, col)
     // source tile origin: image of the output tile's corners under the (affine) index map
     int a0, a1, b0, b1;
@@ -253,9 +261,9 @@ __global__ __launch_bounds__(256) void unrot4_tiled_kernel(const float *__restri
         const int u = s0 + r, v = s1 + tx;
         float val = 0.f;
         if (FWD) {
-            if (u >= 1 && u < P && v >= 0 && v < P) val = src[(long)(u - 1) * P + v];
+            if (u >= 1 && u < P && v >= 0 && v < P) val = IO<TI>::ld(src + (long)(u - 1) * P + v);
         } else {
-            if (u >= 0 && u < P && v >= 0 && v < P) val = src[(long)u * P + v];
+            if (u >= 0 && u < P && v >= 0 && v < P) val = IO<TI>::ld(src + (long)u * P + v);
         }
         tile[r][tx] = val;
     }
@@ -276,11 +284,12 @@ __global__ __launch_bounds__(256) void unrot4_tiled_kernel(const float *__restri
                 val = 0.f;
             }
         }
-        dst[(long)i * P + j] = val;
+        IO<TO>::st(dst + (long)i * P + j, val);
     }
 }
 
-__global__ void unrot4_fwd_kernel(const float *__restrict__ d, float *__restrict__ f, int B, int C, int P) {
+template <typename TI, typename TO>
+__global__ void unrot4_fwd_kernel(const TI *__restrict__ d, TO *__restrict__ f, int B, int C, int P) {
     const long plane = (long)P * P, total = (long)B * 4 * C * plane;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         long t = e;
@@ -292,12 +301,13 @@ __global__ void unrot4_fwd_kernel(const float *__restrict__ d, float *__restrict
         int u, v;
         rot_src((4 - k) & 3, i, j, P, u, v);
         float val = 0.f;
-        if (u >= 1) val = d[(((long)k * B + b) * C + c) * plane + (long)(u - 1) * P + v];
-        f[e] = val;
+        if (u >= 1) val = IO<TI>::ld(d + (((long)k * B + b) * C + c) * plane + (long)(u - 1) * P + v);
+        IO<TO>::st(f + e, val);
     }
 }
 
-__global__ void unrot4_bwd_kernel(const float *__restrict__ gf, float *__restrict__ gd, int B, int C, int P) {
+template <typename TI, typename TO>
+__global__ void unrot4_bwd_kernel(const TI *__restrict__ gf, TO *__restrict__ gd, int B, int C, int P) {
     const long plane = (long)P * P, total = (long)4 * B * C * plane;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         long t = e;
@@ -310,9 +320,9 @@ __global__ void unrot4_bwd_kernel(const float *__restrict__ gf, float *__restric
         if (s + 1 < P) {
             int i, j;
             rot_dst((4 - k) & 3, s + 1, v, P, i, j);
-            g = gf[(((long)b * 4 + k) * C + c) * plane + (long)i * P + j];
+            g = IO<TI>::ld(gf + (((long)b * 4 + k) * C + c) * plane + (long)i * P + j);
         }
-        gd[e] = g;
+        IO<TO>::st(gd + e, g);
     }
 }
 
@@ -579,32 +589,49 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const sprk_adam_item *_
 
 extern "C" {
 
-int sprk_shift_maxpool2_fwd(const float *x, float *y, int NC, int H, int W, int shift, void *stream) {
+int sprk_shift_maxpool2_fwd(const void *x, void *y, int NC, int H, int W, int shift, int io, void *stream) {
     SPRK_REQUIRE(x && y && NC > 0 && H >= 2 && W >= 2 && shift >= 0, "shift_maxpool2_fwd: bad arguments");
     const long total = (long)NC * (H / 2) * (W / 2);
-    if (W % 8 == 0 && H % 2 == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0)) {
-        const int per = (H / 2) * (W / 8);
-        dim3 grid(std::min(sprk::cdiv(per, 256), 64), std::min(NC, 32768));
-        hipLaunchKernelGGL(shift_maxpool2_fwd_v4_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, NC, H, W, shift);
-        return sprk::check_launch("shift_maxpool2_fwd_v4");
-    }
-    hipLaunchKernelGGL(shift_maxpool2_fwd_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y,
-                       NC, H, W, shift);
+    const bool v4 = W % 8 == 0 && H % 2 == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+    const int drc = dispatch_io2(io, [&](auto tx, auto ty) {
+        using TX = decltype(tx);
+        using TY = decltype(ty);
+        if (v4) {
+            const int per = (H / 2) * (W / 8);
+            dim3 grid(std::min(sprk::cdiv(per, 256), 64), std::min(NC, 32768));
+            hipLaunchKernelGGL((shift_maxpool2_fwd_v4_kernel<TX, TY>), grid, dim3(256), 0, (hipStream_t)stream, (const TX *)x,
+                               (TY *)y, NC, H, W, shift);
+        } else {
+            hipLaunchKernelGGL((shift_maxpool2_fwd_kernel<TX, TY>), dim3(sprk::ew_blocks(total)), dim3(256), 0,
+                               (hipStream_t)stream, (const TX *)x, (TY *)y, NC, H, W, shift);
+        }
+        return 0;
+    });
+    SPRK_REQUIRE(drc == 0, "shift_maxpool2_fwd: bad storage types (io)");
     return sprk::check_launch("shift_maxpool2_fwd");
 }
 
-int sprk_shift_maxpool2_bwd(const float *gy, const float *x, float *gx, int NC, int H, int W, int shift, int act,
+int sprk_shift_maxpool2_bwd(const void *gy, const void *x, void *gx, int NC, int H, int W, int shift, int act, int io,
                             void *stream) {
     SPRK_REQUIRE(gy && x && gx && NC > 0 && H >= 2 && W >= 2 && shift >= 0, "shift_maxpool2_bwd: bad arguments");
     const long total = (long)NC * H * W;
-    if (W % 4 == 0 && H % 2 == 0 && ((((uintptr_t)x | (uintptr_t)gx) & 15) == 0) && (((uintptr_t)gy & 7) == 0)) {
-        const int per = H * (W / 4);
-        dim3 grid(std::min(sprk::cdiv(per, 256), 64), std::min(NC, 32768));
-        hipLaunchKernelGGL(shift_maxpool2_bwd_v4_kernel, grid, dim3(256), 0, (hipStream_t)stream, gy, x, gx, NC, H, W, shift, act);
-        return sprk::check_launch("shift_maxpool2_bwd_v4");
-    }
-    hipLaunchKernelGGL(shift_maxpool2_bwd_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, gy,
-                       x, gx, NC, H, W, shift, act);
+    const bool v4 = W % 4 == 0 && H % 2 == 0 && ((((uintptr_t)x | (uintptr_t)gx) & 15) == 0) && (((uintptr_t)gy & 7) == 0);
+    const int drc = dispatch_io3(io, [&](auto tg, auto tx, auto to) {
+        using TG = decltype(tg);
+        using TX = decltype(tx);
+        using TO = decltype(to);
+        if (v4) {
+            const int per = H * (W / 4);
+            dim3 grid(std::min(sprk::cdiv(per, 256), 64), std::min(NC, 32768));
+            hipLaunchKernelGGL((shift_maxpool2_bwd_v4_kernel<TG, TX, TO>), grid, dim3(256), 0, (hipStream_t)stream,
+                               (const TG *)gy, (const TX *)x, (TO *)gx, NC, H, W, shift, act);
+        } else {
+            hipLaunchKernelGGL((shift_maxpool2_bwd_kernel<TG, TX, TO>), dim3(sprk::ew_blocks(total)), dim3(256), 0,
+                               (hipStream_t)stream, (const TG *)gy, (const TX *)x, (TO *)gx, NC, H, W, shift, act);
+        }
+        return 0;
+    });
+    SPRK_REQUIRE(drc == 0, "shift_maxpool2_bwd: bad storage types (io)");
     return sprk::check_launch("shift_maxpool2_bwd");
 }
 
@@ -622,27 +649,39 @@ int sprk_rot4_stack_bwd(const float *gy, float *gx, int B, int C, int P, void *s
     return sprk::check_launch("rot4_stack_bwd");
 }
 
-int sprk_unrot4_shift_concat_fwd(const float *d, float *f, int B, int C, int P, void *stream) {
+int sprk_unrot4_shift_concat_fwd(const void *d, void *f, int B, int C, int P, int io, void *stream) {
     SPRK_REQUIRE(d && f && B > 0 && C > 0 && P > 0, "unrot4_shift_concat_fwd: bad arguments");
-    if (P % 32 == 0 && (long)4 * B * C < 65536) {
-        hipLaunchKernelGGL(unrot4_tiled_kernel<true>, dim3((P / 32) * (P / 32), 4 * B * C), dim3(256), 0,
-                           (hipStream_t)stream, d, f, B, C, P);
-        return sprk::check_launch("unrot4_fwd_tiled");
-    }
-    hipLaunchKernelGGL(unrot4_fwd_kernel, dim3(sprk::ew_blocks(4L * B * C * P * P)), dim3(256), 0, (hipStream_t)stream,
-                       d, f, B, C, P);
+    const bool tiled = P % 32 == 0 && (long)4 * B * C < 65536;
+    const int drc = dispatch_io2(io, [&](auto ti, auto to) {
+        using TI = decltype(ti);
+        using TO = decltype(to);
+        if (tiled)
+            hipLaunchKernelGGL((unrot4_tiled_kernel<true, TI, TO>), dim3((P / 32) * (P / 32), 4 * B * C), dim3(256), 0,
+                               (hipStream_t)stream, (const TI *)d, (TO *)f, B, C, P);
+        else
+            hipLaunchKernelGGL((unrot4_fwd_kernel<TI, TO>), dim3(sprk::ew_blocks(4L * B * C * P * P)), dim3(256), 0,
+                               (hipStream_t)stream, (const TI *)d, (TO *)f, B, C, P);
+        return 0;
+    });
+    SPRK_REQUIRE(drc == 0, "unrot4_shift_concat_fwd: bad storage types (io)");
     return sprk::check_launch("unrot4_fwd");
 }
 
-int sprk_unrot4_shift_concat_bwd(const float *gf, float *gd, int B, int C, int P, void *stream) {
+int sprk_unrot4_shift_concat_bwd(const void *gf, void *gd, int B, int C, int P, int io, void *stream) {
     SPRK_REQUIRE(gf && gd && B > 0 && C > 0 && P > 0, "unrot4_shift_concat_bwd: bad arguments");
-    if (P % 32 == 0 && (long)4 * B * C < 65536) {
-        hipLaunchKernelGGL(unrot4_tiled_kernel<false>, dim3((P / 32) * (P / 32), 4 * B * C), dim3(256), 0,
-                           (hipStream_t)stream, gf, gd, B, C, P);
-        return sprk::check_launch("unrot4_bwd_tiled");
-    }
-    hipLaunchKernelGGL(unrot4_bwd_kernel, dim3(sprk::ew_blocks(4L * B * C * P * P)), dim3(256), 0, (hipStream_t)stream,
-                       gf, gd, B, C, P);
+    const bool tiled = P % 32 == 0 && (long)4 * B * C < 65536;
+    const int drc = dispatch_io2(io, [&](auto ti, auto to) {
+        using TI = decltype(ti);
+        using TO = decltype(to);
+        if (tiled)
+            hipLaunchKernelGGL((unrot4_tiled_kernel<false, TI, TO>), dim3((P / 32) * (P / 32), 4 * B * C), dim3(256), 0,
+                               (hipStream_t)stream, (const TI *)gf, (TO *)gd, B, C, P);
+        else
+            hipLaunchKernelGGL((unrot4_bwd_kernel<TI, TO>), dim3(sprk::ew_blocks(4L * B * C * P * P)), dim3(256), 0,
+                               (hipStream_t)stream, (const TI *)gf, (TO *)gd, B, C, P);
+        return 0;
+    });
+    SPRK_REQUIRE(drc == 0, "unrot4_shift_concat_bwd: bad storage types (io)");
     return sprk::check_launch("unrot4_bwd");
 }
 

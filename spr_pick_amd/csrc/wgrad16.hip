@@ -1,7 +1,8 @@
 // 16-bit-operand backward-weight of the 3x3 stride-1 layers (gfx950 / MI355X):
 //   dW[cout][cin][ky][kx] = sum over images and pixels of  gy[n][cout][r][c] * x[n][cin][r + ky - padT][c + kx - padL]
-// on v_mfma_f32_16x16x32_{bf16,f16}.  As in conv16.hip the tensors are fp32 in HBM and only the two operands of each
-// product are rounded (round to nearest even); products exact, sums fp32.
+// on v_mfma_f32_16x16x32_{bf16,f16}.  As in conv16.hip the activation tensors (x, gy) are fp32 in HBM with the two operands
+// of each product rounded on the way in (round to nearest even), or — X16 — 16-bit tensors of the operand type already
+// (half the bytes, no conversion); products exact, sums fp32, dW fp32.
 //
 // GEMM view: D[m = cout][n = cin] per tap, the reduced dimension k is the PIXEL.  A lane's 8 consecutive k are 8
 // consecutive pixels of one row of one channel plane, for both operands:
@@ -22,6 +23,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -52,7 +54,7 @@ constexpr int kRegionPx = 128;   // output pixels per region = 4 k-steps of 32
 constexpr int kGyStride = 272;   // bytes per cout row of the gy tile: 128 pixels x 2 B + 16 (bank spread)
 
 struct Wg16Args {
-    const float *x, *x2, *gy;
+    const void *x, *x2, *gy; // fp32, or (X16) 16-bit tensors of the operand type
     float *partial;          // [parts][Cout][CinTot][9]
     int N, C1, C2, H, W, Cout, padT, padL;
     int regX, regY;          // regions per row of regions / per column (region = RH rows x RW columns = 128 pixels)
@@ -67,8 +69,9 @@ struct Wg16Args {
 // The x tile is a ROLLING window of SLOTS = 2 RH + 2 tile rows per channel: consecutive regions of a strip share RH + 2
 // - RH = 2 halo rows... precisely: region j reads tile rows j RH .. j RH + RH + 1 and only the RH rows below are new, so
 // x is fetched once (the first version re-fetched the halo rows of every region: 2x the bytes at 2-row regions).
-template <typename T, int MC, int LGRW>   // MC: output-channel tiles (6: 49..96 channels, 3: 33..48)
+template <typename T, int MC, int LGRW, bool X16>   // MC: output-channel tiles (6: 49..96 channels, 3: 33..48)
 __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
+    constexpr int ES = X16 ? 2 : 4;                            // bytes per element of x / gy in HBM
     using V8 = typename OpW<T>::v8;
     typedef const __attribute__((address_space(3))) V8 *lds_v8p;
     constexpr int RW = 1 << LGRW, RH = kRegionPx / RW, SLOTS = 2 * RH + 2;
@@ -93,18 +96,31 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     const int ldsGy = lds_addr(smem), ldsX = ldsGy + 2 * gyBytes;
 
     typedef unsigned u32x4 __attribute__((__vector_size__(16)));
+    typedef unsigned u32x2 __attribute__((__vector_size__(8)));
     typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u16x4 *lds_u16x4w;
-    auto cvt4 = [&](const u32x4 &v) {   // 4 fp32 -> 4 x 16 bit (8 bytes)
-        typedef T t4 __attribute__((ext_vector_type(4)));
-        // (element first into a scalar: __builtin_bit_cast applied to a vector element expression reads element 0)
-        const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
-        t4 r;
-        r[0] = (T)__uint_as_float(e0);
-        r[1] = (T)__uint_as_float(e1);
-        r[2] = (T)__uint_as_float(e2);
-        r[3] = (T)__uint_as_float(e3);
-        return __builtin_bit_cast(u16x4, r);
+    // one fetched item = 4 consecutive pixels: 16 bytes of fp32 or 8 bytes of 16-bit values
+    using fetch_t = typename std::conditional<X16, u32x2, u32x4>::type;
+    auto load_item = [&](const rsrc_t r, int voff, int soff) -> fetch_t {
+        if constexpr (X16)
+            return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        else
+            return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    };
+    auto cvt4 = [&](const fetch_t &v) {   // -> 4 x 16 bit (8 bytes): fp32 values are rounded here, 16-bit ones pass through
+        if constexpr (X16) {
+            return __builtin_bit_cast(u16x4, v);
+        } else {
+            typedef T t4 __attribute__((ext_vector_type(4)));
+            // (element first into a scalar: __builtin_bit_cast applied to a vector element expression reads element 0)
+            const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+            t4 r;
+            r[0] = (T)__uint_as_float(e0);
+            r[1] = (T)__uint_as_float(e1);
+            r[2] = (T)__uint_as_float(e2);
+            r[3] = (T)__uint_as_float(e3);
+            return __builtin_bit_cast(u16x4, r);
+        }
     };
 
     // ---- per-thread item geometry (16-byte items: consecutive lanes on consecutive 16 bytes) -------------------------
@@ -115,10 +131,10 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     {
         const int p = (tid & 31) * 4;
         const int rr = p >> LGRW, cc = p & (RW - 1);
-        gyc0 = ((gyco * a.H + rr) * a.W + cc) * 4;
+        gyc0 = ((gyco * a.H + rr) * a.W + cc) * ES;
         gyl0 = gyco * kGyStride + (tid & 31) * 8;
     }
-    const int gycStep = 16 * HW * 4;
+    const int gycStep = 16 * HW * ES;
     // x items: byte offset inside the item's source relative to (tile row 0, column block), or the out-of-range marker |
     // packed: LDS offset (bits 0-19), tile row within the fetch (bits 20-23, 15 = no item), source 2 flag (bit 24)
     int xc[XN], xp[XN];
@@ -133,11 +149,11 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
                             !(a.diag & 1);
             const bool s1 = ch < a.C1;
             const int cc = s1 ? ch : ch - a.C1;
-            xc[i] = ok ? (cc * a.H * a.W + ix) * 4 : (int)0x80000000;
+            xc[i] = ok ? (cc * a.H * a.W + ix) * ES : (int)0x80000000;
             xp[i] = (cl * a.xcs + g4 * 8) | ((rloc < RH ? rloc : 15) << 20) | (s1 ? 0 : 1 << 24);
         }
     };
-    u32x4 fg[GYN], fx[XN];
+    fetch_t fg[GYN], fx[XN];
     // fetch `rows` tile rows starting at tile row t0 (image row y0 + t0) of the strip: rows outside the image are zeros
     auto fetch_x = [&](const rsrc_t r1, const rsrc_t r2, int y0, int t0, int rows) {
 #pragma unroll
@@ -145,14 +161,14 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
             const int rloc = (xp[i] >> 20) & 15;
             const int iy = y0 + t0 + rloc;
             const bool ok = rloc < rows && (unsigned)iy < (unsigned)a.H && xc[i] >= 0;
-            const int off = ok ? xc[i] + iy * a.W * 4 : (int)0x80000000;
+            const int off = ok ? xc[i] + iy * a.W * ES : (int)0x80000000;
             if (a.C2) {
                 const bool s2 = (xp[i] >> 24) & 1;
-                const u32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(r1, s2 ? (int)0x80000000 : off, 0, 0);
-                const u32x4 v2 = __builtin_amdgcn_raw_buffer_load_b128(r2, s2 ? off : (int)0x80000000, 0, 0);
+                const fetch_t v1 = load_item(r1, s2 ? (int)0x80000000 : off, 0);
+                const fetch_t v2 = load_item(r2, s2 ? off : (int)0x80000000, 0);
                 fx[i] = v1 | v2;
             } else {
-                fx[i] = __builtin_amdgcn_raw_buffer_load_b128(r1, off, 0, 0);
+                fx[i] = load_item(r1, off, 0);
             }
         }
     };
@@ -168,8 +184,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     auto fetch_gy = [&](const rsrc_t rg, int org) {
 #pragma unroll
         for (int i = 0; i < GYN; ++i)
-            fg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, gyco + 16 * i < gyLim ? gyc0 + i * gycStep : (int)0x80000000,
-                                                          org, 0);
+            fg[i] = load_item(rg, gyco + 16 * i < gyLim ? gyc0 + i * gycStep : (int)0x80000000, org);
     };
     auto store_gy = [&](int b) {
 #pragma unroll
@@ -211,15 +226,16 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
         const int ry0 = sgi * a.segLen, nreg = min(a.segLen, a.regY - ry0);
         const int y0 = ry0 * RH - a.padT;                  // image row of tile row 0 of this unit
         x_items(c0);
-        const rsrc_t rg = make_rsrc(a.gy + (long)n * a.Cout * HW);
-        const rsrc_t r1 = make_rsrc(a.x + (long)n * a.C1 * HW);
-        const rsrc_t r2 = make_rsrc(a.C2 ? a.x2 + (long)n * a.C2 * HW : a.x);
+        const char *xb = (const char *)a.x, *x2b = (const char *)a.x2, *gyb = (const char *)a.gy;
+        const rsrc_t rg = make_rsrc(gyb + (long)n * a.Cout * HW * ES);
+        const rsrc_t r1 = make_rsrc(xb + (long)n * a.C1 * HW * ES);
+        const rsrc_t r2 = make_rsrc(a.C2 ? x2b + (long)n * a.C2 * HW * ES : xb);
         __syncthreads();                                   // the previous unit's last region has been consumed
         // prologue: the two halo rows on top, then region 0's RH rows and its gy tile
         fetch_x(r1, r2, y0, 0, 2);
         store_x(0, 2);
         fetch_x(r1, r2, y0, 2, RH);
-        fetch_gy(rg, ((ry0 * RH) * a.W + c0) * 4);
+        fetch_gy(rg, ((ry0 * RH) * a.W + c0) * ES);
         store_x(2, RH);
         store_gy(0);
         for (int j = 0; j < nreg; ++j) {
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
             const bool more = j + 1 < nreg;
             if (more) {                                    // next region: in flight under this region's MFMAs
                 fetch_x(r1, r2, y0, 2 + (j + 1) * RH, RH);
-                fetch_gy(rg, (((ry0 + j + 1) * RH) * a.W + c0) * 4);
+                fetch_gy(rg, (((ry0 + j + 1) * RH) * a.W + c0) * ES);
             }
             if (!(a.diag & 4)) {
                 const int ga = alane + (j & 1) * gyBytes;
@@ -323,15 +339,16 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
 // Regions of 64 pixels are dealt to the workgroups in contiguous runs; the next region's 12 x 16 bytes per lane are
 // in flight under the current region's MFMAs, converted and written to the other LDS stage.
 struct Wg1Args {
-    const float *x, *gy;
+    const void *x, *gy;      // fp32, or (X16) 16-bit tensors of the operand type
     float *partial;          // [parts][Cout][Cin]
     int N, Cin, Cout, HW;
     int regPerImg, nRegions, perPart;
     int diag;
 };
 
-template <typename T, int WM, int MC, int NC>
+template <typename T, int WM, int MC, int NC, bool X16>
 __global__ __launch_bounds__(kWgThreads) void wgrad16_1x1_kernel(const Wg1Args a) {
+    constexpr int ES = X16 ? 2 : 4;
     using V8 = typename OpW<T>::v8;
     typedef const __attribute__((address_space(3))) V8 *lds_v8p;
     constexpr int WN = 8 / WM;
@@ -348,32 +365,44 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_1x1_kernel(const Wg1Args a
     const int ldsGy = lds_addr(smem), ldsX = ldsGy + 2 * gyBytes;
 
     typedef unsigned u32x4 __attribute__((__vector_size__(16)));
+    typedef unsigned u32x2 __attribute__((__vector_size__(8)));
     typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u16x4 *lds_u16x4w;
-    auto cvt4 = [&](const u32x4 &v) {
-        typedef T t4 __attribute__((ext_vector_type(4)));
-        const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
-        t4 r;
-        r[0] = (T)__uint_as_float(e0);
-        r[1] = (T)__uint_as_float(e1);
-        r[2] = (T)__uint_as_float(e2);
-        r[3] = (T)__uint_as_float(e3);
-        return __builtin_bit_cast(u16x4, r);
+    using fetch_t = typename std::conditional<X16, u32x2, u32x4>::type;
+    auto load_item = [&](const rsrc_t r, int voff, int soff) -> fetch_t {
+        if constexpr (X16)
+            return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        else
+            return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    };
+    auto cvt4 = [&](const fetch_t &v) {
+        if constexpr (X16) {
+            return __builtin_bit_cast(u16x4, v);
+        } else {
+            typedef T t4 __attribute__((ext_vector_type(4)));
+            const unsigned e0 = v[0], e1 = v[1], e2 = v[2], e3 = v[3];
+            t4 r;
+            r[0] = (T)__uint_as_float(e0);
+            r[1] = (T)__uint_as_float(e1);
+            r[2] = (T)__uint_as_float(e2);
+            r[3] = (T)__uint_as_float(e3);
+            return __builtin_bit_cast(u16x4, r);
+        }
     };
     // item i of this thread: channel row (tid >> 4) + 32 i, pixel group tid & 15
     const int row0 = tid >> 4, g4 = tid & 15;
-    const int goff0 = ((co0 + row0) * a.HW + g4 * 4) * 4, xoff0 = ((ci0 + row0) * a.HW + g4 * 4) * 4;
-    const int rstep = 32 * a.HW * 4;
+    const int goff0 = ((co0 + row0) * a.HW + g4 * 4) * ES, xoff0 = ((ci0 + row0) * a.HW + g4 * 4) * ES;
+    const int rstep = 32 * a.HW * ES;
     const int lrow = row0 * kRow + g4 * 8;
     const int gyLim = (a.diag & 1) ? 0 : a.Cout - co0, xLim = (a.diag & 1) ? 0 : a.Cin - ci0;
-    u32x4 fg[GN], fx[XN];
+    fetch_t fg[GN], fx[XN];
     auto fetch = [&](const rsrc_t rg, const rsrc_t rx, int org) {
 #pragma unroll
         for (int i = 0; i < GN; ++i)
-            fg[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, row0 + 32 * i < gyLim ? goff0 + i * rstep : (int)0x80000000, org, 0);
+            fg[i] = load_item(rg, row0 + 32 * i < gyLim ? goff0 + i * rstep : (int)0x80000000, org);
 #pragma unroll
         for (int i = 0; i < XN; ++i)
-            fx[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, row0 + 32 * i < xLim ? xoff0 + i * rstep : (int)0x80000000, org, 0);
+            fx[i] = load_item(rx, row0 + 32 * i < xLim ? xoff0 + i * rstep : (int)0x80000000, org);
     };
     auto store = [&](int b) {
 #pragma unroll
@@ -394,9 +423,9 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_1x1_kernel(const Wg1Args a
     const int r0 = blockIdx.x * a.perPart, r1 = min(a.nRegions, r0 + a.perPart);
     auto rsrcs = [&](int r, rsrc_t &rg, rsrc_t &rx, int &org) {
         const int n = r / a.regPerImg, pb = r - n * a.regPerImg;
-        rg = make_rsrc(a.gy + (long)n * a.Cout * a.HW);
-        rx = make_rsrc(a.x + (long)n * a.Cin * a.HW);
-        org = pb * kPx * 4;
+        rg = make_rsrc((const char *)a.gy + (long)n * a.Cout * a.HW * ES);
+        rx = make_rsrc((const char *)a.x + (long)n * a.Cin * a.HW * ES);
+        org = pb * kPx * ES;
     };
     if (r0 < r1) {
         rsrc_t rg, rx;
@@ -550,7 +579,7 @@ size_t wgrad16_ws_bytes(const Wgrad16Call &c) {
     return plan_wg16(c, &p) ? p.wsBytes : plan_wg1x1(c, &p1) ? p1.wsBytes : 0;
 }
 
-static int wgrad16_run_1x1(const Wgrad16Call &c, const Plan1 &p, const float *x, const float *gy, float *gw, void *ws,
+static int wgrad16_run_1x1(const Wgrad16Call &c, const Plan1 &p, const void *x, const void *gy, float *gw, void *ws,
                            size_t ws_bytes, sprk_reduce_item *item, hipStream_t s) {
     if (ws_bytes < p.wsBytes || !ws) {
         set_error("wgrad16 (1x1): workspace too small (%zu < %zu)", ws_bytes, p.wsBytes);
@@ -578,10 +607,11 @@ static int wgrad16_run_1x1(const Wgrad16Call &c, const Plan1 &p, const float *x,
     };
     auto pick = [&](auto tag) {
         using T = decltype(tag);
-        return p.wide ? go(wgrad16_1x1_kernel<T, 4, 3, 6>) : go(wgrad16_1x1_kernel<T, 2, 3, 6>);
+        if (c.x16) return p.wide ? go(wgrad16_1x1_kernel<T, 4, 3, 6, true>) : go(wgrad16_1x1_kernel<T, 2, 3, 6, true>);
+        return p.wide ? go(wgrad16_1x1_kernel<T, 4, 3, 6, false>) : go(wgrad16_1x1_kernel<T, 2, 3, 6, false>);
     };
     prof_begin(c.kclass, c.flops, s);
-    prof_bytes(4.0 * c.N * ((double)(c.C1 + c.C2) * c.H * c.W + (double)c.Cout * c.Hout * c.Wout));
+    prof_bytes((c.x16 ? 2.0 : 4.0) * c.N * ((double)(c.C1 + c.C2) * c.H * c.W + (double)c.Cout * c.Hout * c.Wout));
     const int rc = (c.dtype & SPRK_DT_MASK) == SPRK_DT_BF16 ? pick(__bf16{}) : pick(_Float16{});
     if (rc) return rc;
     prof_end(c.kclass, s);
@@ -593,7 +623,7 @@ static int wgrad16_run_1x1(const Wgrad16Call &c, const Plan1 &p, const float *x,
 
 long wgrad16_launches() { return g_wgrad16_launches.load(); }
 
-int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const float *gy, float *gw, void *ws,
+int wgrad16_run(const Wgrad16Call &c, const void *x, const void *x2, const void *gy, float *gw, void *ws,
                 size_t ws_bytes, sprk_reduce_item *item, hipStream_t s) {
     PlanW p;
     if (!plan_wg16(c, &p)) {
@@ -626,12 +656,17 @@ int wgrad16_run(const Wgrad16Call &c, const float *x, const float *x2, const flo
     };
     auto pick = [&](auto tag) {
         using T = decltype(tag);
-        if (p.lgRW == 6) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 6>) : go(wgrad16_kernel<T, 3, 6>);
-        if (p.lgRW == 5) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 5>) : go(wgrad16_kernel<T, 3, 5>);
-        return p.MC == 6 ? go(wgrad16_kernel<T, 6, 4>) : go(wgrad16_kernel<T, 3, 4>);
+        if (c.x16) {
+            if (p.lgRW == 6) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 6, true>) : go(wgrad16_kernel<T, 3, 6, true>);
+            if (p.lgRW == 5) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 5, true>) : go(wgrad16_kernel<T, 3, 5, true>);
+            return p.MC == 6 ? go(wgrad16_kernel<T, 6, 4, true>) : go(wgrad16_kernel<T, 3, 4, true>);
+        }
+        if (p.lgRW == 6) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 6, false>) : go(wgrad16_kernel<T, 3, 6, false>);
+        if (p.lgRW == 5) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 5, false>) : go(wgrad16_kernel<T, 3, 5, false>);
+        return p.MC == 6 ? go(wgrad16_kernel<T, 6, 4, false>) : go(wgrad16_kernel<T, 3, 4, false>);
     };
     prof_begin(c.kclass, c.flops, s);
-    prof_bytes(4.0 * c.N * ((double)(c.C1 + c.C2) * c.H * c.W + (double)c.Cout * c.Hout * c.Wout));
+    prof_bytes((c.x16 ? 2.0 : 4.0) * c.N * ((double)(c.C1 + c.C2) * c.H * c.W + (double)c.Cout * c.Hout * c.Wout));
     const int rc = dt == SPRK_DT_BF16 ? pick(__bf16{}) : pick(_Float16{});
     if (rc) return rc;
     prof_end(c.kclass, s);

@@ -122,8 +122,10 @@ class Denoiser(nn.Module):
                                                                         blindspot=False, detect=False))
 
     def set_conv_dtype(self, dtype):
-        """"f32" (default) | "bf16" | "f16": operand precision of the U-Nets' MFMA convolutions (BASELINE configs[4];
-        networks.set_conv_dtype).  Parameters, activations, gradients and the optimiser stay fp32."""
+        """"f32" (default) | "bf16" | "f16" | "mixed16": operand precision of the U-Nets' MFMA convolutions AND storage type
+        of the activation / activation-gradient tensors between their layers (BASELINE configs[4]; networks.set_conv_dtype;
+        "<type>/operands": fp32 tensors, operands rounded on the way in).  Parameters, their gradients, the optimiser, the
+        detector and everything behind the U-Nets' output convolutions stay fp32."""
         from .networks import set_conv_dtype
         self.conv_dtype = dtype
         return set_conv_dtype(self, dtype)

@@ -18,6 +18,7 @@ upsample + concat is fused into the following conv's loads, ``fill()``/``unfill(
 instead of rewriting module attributes, and eval-mode BatchNorm is folded into the conv epilogue.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -56,6 +57,7 @@ class Conv2d(nn.Module):
         self.act = act
         self.mfma_dtype = 0      # _lib.DT_*: operand precision of this layer's MFMA kernels (set_conv_dtype) ...
         self.mfma_dtype_nograd = 0   # ... while autograd records (training) / under no_grad (inference)
+        self.store16 = False         # 16-bit modes: write the output as a bf16 / fp16 tensor where a kernel exists (ops.conv2d)
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
@@ -79,7 +81,8 @@ class Conv2d(nn.Module):
         # of a micrograph gets the very arithmetic the whole micrograph gets (Denoiser._tiled_networks)
         dtype = self.mfma_dtype if torch.is_grad_enabled() else (self.mfma_dtype_nograd | DT_PIN)
         return ops.conv2d(x, self.weight, self.bias, x2=skip, up1=up, stride=self.stride, dil=self.dilation,
-                          pad=self._pad(), act=self.act, up_out=up_out, dtype=dtype, x_act=x_act, premasked=premasked)
+                          pad=self._pad(), act=self.act, up_out=up_out, dtype=dtype, x_act=x_act, premasked=premasked,
+                          store16=self.store16 and (dtype & 0xff) != 0)
 
     def extra_repr(self):
         return "%d, %d, kernel_size=%s, stride=%d, padding=%d, dilation=%d, act=%d%s" % (
@@ -220,6 +223,9 @@ def set_conv_dtype(module, dtype):
     gradients: a run trained with fp16 operands end to end leaves the sigma-net at its floor and reaches AP 0.65 where
     fp32 and bf16 reach 0.93 (profiles/r04_full_pipeline.json)."""
     from ._lib import DT_BF16, DT_F16, DTYPES
+    storage = os.environ.get("SPRK_STORE16", "1") != "0"
+    if isinstance(dtype, str) and dtype.endswith("/operands"):       # "bf16/operands": fp32 tensors, 16-bit operands only
+        dtype, storage = dtype[:-len("/operands")], False
     if dtype == "mixed16":
         code, code_ng = DT_BF16, DT_F16
     else:
@@ -230,6 +236,9 @@ def set_conv_dtype(module, dtype):
             for name, m in net.named_modules():
                 if isinstance(m, Conv2d) and not name.startswith("output_conv"):
                     m.mfma_dtype, m.mfma_dtype_nograd = code, code_ng
+                    # 16-bit ACTIVATION tensors between the U-Net's layers (round 4): every layer stores its output in the
+                    # operand type, except the one in front of the fp32 output convolution (output_block.2)
+                    m.store16 = storage and (code & 0xff) != 0 and name != "output_block.2"
                     n += 1
     return n
 

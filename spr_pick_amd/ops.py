@@ -41,6 +41,14 @@ def _need_gpu(*ts):
                                  "there is no CPU path" % (t.dtype, t.device))
 
 
+def _need_act(*ts):
+    """Activation tensors: float32, or — the 16-bit storage modes — bfloat16 / float16, on the GPU."""
+    for t in ts:
+        if t is not None and (not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16, torch.float16)):
+            raise _lib.SprkError("spr_pick_amd ops need float32 / bfloat16 / float16 activation tensors on the GPU (got %s on "
+                                 "%s); there is no CPU path" % (t.dtype, t.device))
+
+
 _GRAD_DEST = None
 
 
@@ -205,7 +213,8 @@ def make_geom(x, x2, w, up1, stride, dil, pad, out_hw=None, dtype=0):
 def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None, res=None, res_off=0, up_out=False):
     """Raw forward launch (no autograd).  Returns y [N,Cout,Hout,Wout] ([N,Cout,2Hout,2Wout] with
     ``up_out``: nearest x2 upsampling fused into the store)."""
-    _need_gpu(x, x2, w, bias, scale, shift, res)
+    _need_act(x, x2)
+    _need_gpu(w, bias, scale, shift, res)
     ws = None
     if _WPREP is not None:
         ep = torch_ops._epilogue(bias, scale, shift, res, int(res_off), int(act), up_out)
@@ -213,16 +222,65 @@ def conv2d_forward(x, x2, w, g, bias=None, act=ACT_NONE, scale=None, shift=None,
     return _S.conv2d_fwd(x, x2, w, bias, scale, shift, res, geom_list(g), int(res_off), int(act), 1 if up_out else 0, ws)
 
 
+_F32 = torch.float32
+_STORAGE = _lib.DT_X16 | _lib.DT_Y16
+_CAP16 = {}
+
+
+def storage16_caps(g, up_out=False):
+    """Which calls of this layer have kernels for 16-bit ACTIVATION tensors (include/sprk.h, SPRK_DT_X16 / _Y16):
+    bit 0 forward, bit 1 backward-data, bit 2 backward-weight.  0 for fp32 operands.  Cached per geometry."""
+    if (g.dtype & 0xff) == 0:
+        return 0
+    fields = geom_list(g)
+    key = tuple(fields[:15]) + (g.dtype & (0xff | _lib.DT_FORCE | _lib.DT_NAIVE), bool(up_out))
+    caps = _CAP16.get(key)
+    if caps is None:
+        q = ConvGeom(*fields)
+        q.dtype = g.dtype & (0xff | _lib.DT_FORCE | _lib.DT_NAIVE | _lib.DT_PIN)
+        ep = ConvEpilogue(None, None, None, None, 0, 0, 0, ACT_NONE, 1 if up_out else 0)
+        caps = int(_lib.lib().sprk_conv2d_storage16(ctypes.byref(q), ctypes.byref(ep)))
+        _CAP16[key] = caps
+    return caps
+
+
+def _with_dtype(g, dtype):
+    q = ConvGeom(*geom_list(g))
+    q.dtype = dtype
+    return q
+
+
 class _Conv2dFn(torch.autograd.Function):
+    """Storage types (round 4): with 16-bit operands (dtype bf16 / fp16) the activation tensors may themselves be 16-bit
+    tensors.  A call whose kernel exists for them (storage16_caps) takes 16-bit inputs as they are and — store16 — writes
+    a 16-bit output; any other call converts what it is handed to fp32 first, so every combination of layers works and
+    the fast path is simply the one without conversions.  Gradients have the storage type of the tensor they belong to."""
+
     @staticmethod
-    def forward(ctx, x, x2, w, bias, up1, stride, dil, pad, act, up_out, dtype, x_act=ACT_NONE, premasked=False):
+    def forward(ctx, x, x2, w, bias, up1, stride, dil, pad, act, up_out, dtype, x_act=ACT_NONE, premasked=False,
+                store16=False):
         ctx.x_act, ctx.premasked = x_act, premasked
+        ctx.in_dtypes = (x.dtype, None if x2 is None else x2.dtype)
         x = x.contiguous()
         x2 = None if x2 is None else x2.contiguous()
         w = w.contiguous()
         g = make_geom(x, x2, w, up1, stride, dil, pad, dtype=dtype)
+        c16 = dtype & 0xff
+        caps = storage16_caps(g, up_out) if c16 else 0
+        t16 = torch_ops.TORCH_OF[c16] if c16 else None
+        in16 = x.dtype != _F32 or (x2 is not None and x2.dtype != _F32)
+        if in16 and (caps & 1) and all(t is None or t.dtype in (_F32, t16) for t in (x, x2)):
+            # the kernel reads 16-bit tensors: both sources in that type (a small fp32 source — the raw image — is cast)
+            x = x if x.dtype == t16 else x.to(t16)
+            x2 = x2 if x2 is None or x2.dtype == t16 else x2.to(t16)
+        elif in16:
+            x = x.float()
+            x2 = None if x2 is None else x2.float()
+            in16 = False
+        g.dtype |= (_lib.DT_X16 if in16 else 0) | (_lib.DT_Y16 if (store16 and (caps & 1)) else 0)
         y = conv2d_forward(x, x2, w, g, bias=bias, act=act, up_out=up_out)
         ctx.geom = g
+        ctx.caps = caps
         ctx.act = act
         ctx.up_out = up_out
         ctx.has_bias = bias is not None
@@ -233,7 +291,11 @@ class _Conv2dFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, x2, w, y, bias = ctx.saved_tensors
         g = ctx.geom
-        _need_gpu(gy)
+        base = g.dtype & ~_STORAGE                    # operand type + FORCE / NAIVE bits, no storage bits
+        c16 = base & 0xff
+        t16 = torch_ops.TORCH_OF[c16] if c16 else None
+        caps = ctx.caps
+        _need_act(gy)
         # a gradient that is a channel slice of a concat layer's input gradient (dense planes, strided images) is read
         # in place by act_bwd; everything else wants it dense
         if not (ctx.act != ACT_NONE or ctx.up_out):
@@ -252,22 +314,31 @@ class _Conv2dFn(torch.autograd.Function):
                 gb, defer_b = _grad_dest(bias)
             if not want_gpre:
                 gy = gy.contiguous()
-            out = _S.act_bwd(gy, y, act_here, [g.N, g.Cout, g.Hout, g.Wout], up2, want_gpre, gb, defer_b)
+            out = _S.act_bwd(gy, y, act_here, [g.N, g.Cout, g.Hout, g.Wout], up2, want_gpre, gb, defer_b, torch_ops.code(gy))
             gpre = out if want_gpre else gy
         else:
             gpre = gy.contiguous()
         if ctx.needs_input_grad[2]:
             gw, defer_w = _grad_dest(w)
-            _S.conv2d_bwd_weight(x, x2, gpre, geom_list(g), gw, defer_w)
+            xs, x2s, gs, gq = x, x2, gpre, _with_dtype(g, base)
+            if any(t is not None and t.dtype != _F32 for t in (xs, x2s, gs)):
+                if (caps & 4) and all(t is None or t.dtype in (_F32, t16) for t in (xs, x2s, gs)):
+                    xs, gs = (t if t.dtype == t16 else t.to(t16) for t in (xs, gs))
+                    x2s = x2s if x2s is None or x2s.dtype == t16 else x2s.to(t16)
+                    gq.dtype = base | _lib.DT_X16
+                else:       # no 16-bit-storage kernel for this layer's backward-weight: fp32 tensors
+                    xs, gs = xs.float(), gs.float()
+                    x2s = None if x2s is None else x2s.float()
+            _S.conv2d_bwd_weight(xs, x2s, gs, geom_list(gq), gw, defer_w)
         need0 = ctx.needs_input_grad[0]
         need1 = x2 is not None and ctx.needs_input_grad[1]
         if need0 or need1:
-            gd, wd = g, w
+            gd, wd = _with_dtype(g, base), w
             if g.C2 and not need1:
                 # the skip source needs no gradient (the raw image x0 of decode_block_1): only the
                 # first C1 input channels are back-propagated
                 gd = ConvGeom(g.N, g.C1, 0, g.Hin, g.Win, g.up1, g.Cout, g.Hout, g.Wout, g.KH, g.KW, g.stride, g.dil,
-                              g.pad_top, g.pad_left, g.dtype)
+                              g.pad_top, g.pad_left, base)
                 wd = w[:, :g.C1].contiguous()
             gsrc = gpre
             if gd.stride > 1 and gd.C1 + gd.C2 >= 16 and not (gd.dtype & _lib.DT_NAIVE):
@@ -281,13 +352,24 @@ class _Conv2dFn(torch.autograd.Function):
                 gsrc[:, :, ::st, ::st] = gpre
                 gd = ConvGeom(gd.N, gd.C1, gd.C2, gd.Hin, gd.Win, gd.up1, gd.Cout, H1, W1, gd.KH, gd.KW, 1, gd.dil,
                               gd.pad_top, gd.pad_left, gd.dtype)
+            # storage types of this call: the gradient it reads as it is (if a kernel exists for that), the gradient it
+            # writes in the type of the tensor it belongs to
+            want16 = t16 is not None and ctx.in_dtypes[0] == t16
+            if (caps & 2) and gd.stride == 1 and gsrc.dtype in (_F32, t16):
+                gd.dtype = base | (_lib.DT_X16 if gsrc.dtype == t16 else 0) | (_lib.DT_Y16 if want16 else 0)
+            elif gsrc.dtype != _F32:
+                gsrc = gsrc.float()
             # x_act: x is the output of an activated layer that this convolution alone consumes — its activation
             # backward is fused into this backward-data call (the saved input is the mask)
             masked = ctx.x_act != ACT_NONE and gd.C2 == 0 and not gd.up1
             ws_b = None
             if wd is w:      # (a sliced weight is a new tensor every step: nothing to keep)
                 gd, ws_b = _prep_bwd(w, gd)
-            gin = _S.conv2d_bwd_data(gsrc, wd, geom_list(gd), x if masked else None, ctx.x_act if masked else ACT_NONE, ws_b)
+            mask = None
+            if masked:
+                mt = t16 if (gd.dtype & _lib.DT_Y16) else _F32
+                mask = x if x.dtype == mt else x.to(mt)
+            gin = _S.conv2d_bwd_data(gsrc, wd, geom_list(gd), mask, ctx.x_act if masked else ACT_NONE, ws_b)
             if ctx.x_act != ACT_NONE and not masked:
                 raise _lib.SprkError("conv2d: x_act needs a single, full-resolution input source")
             if gd.C2 == 0 and not gd.up1:
@@ -297,14 +379,20 @@ class _Conv2dFn(torch.autograd.Function):
                 # act_bwd of the producing layers, autograd's accumulation — read strided images in place)
                 gx, gx2 = gin[:, :gd.C1], gin[:, gd.C1:]
             else:
-                gx, gx2 = _S.concat_up_bwd(gin, gd.C1, gd.C2, gd.up1, list(x.shape), list(x2.shape) if gd.C2 else [0])
+                gx, gx2 = _S.concat_up_bwd(gin.float() if gin.dtype != _F32 else gin, gd.C1, gd.C2, gd.up1, list(x.shape),
+                                           list(x2.shape) if gd.C2 else [0])
                 if not gd.C2:
                     gx2 = None
-        return gx, gx2, gw, gb, None, None, None, None, None, None, None, None, None
+            # (a source that arrived in another storage type than the kernel's gets its gradient in ITS type)
+            if gx is not None and gx.dtype != ctx.in_dtypes[0]:
+                gx = gx.to(ctx.in_dtypes[0])
+            if gx2 is not None and ctx.in_dtypes[1] is not None and gx2.dtype != ctx.in_dtypes[1]:
+                gx2 = gx2.to(ctx.in_dtypes[1])
+        return gx, gx2, gw, gb, None, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, bias=None, x2=None, up1=False, stride=1, dil=1, pad=(0, 0, 0, 0), act=ACT_NONE, up_out=False,
-           dtype=0, x_act=ACT_NONE, premasked=False):
+           dtype=0, x_act=ACT_NONE, premasked=False, store16=False):
     """y = act(conv(cat(up2(x) if up1 else x, x2), w) + bias); pad = (top, bottom, left, right).
     up_out: return nearest-x2-upsampled y (the upsampling is fused into the conv's stores).
     dtype: _lib.DT_F32 / DT_BF16 / DT_F16 — precision of the MFMA operands in forward, backward-data and
@@ -312,11 +400,12 @@ def conv2d(x, w, bias=None, x2=None, up1=False, stride=1, dil=1, pad=(0, 0, 0, 0
     Activation backward fused into the neighbours (conv -> conv and conv -> pool chains; a pair of promises the CALLER
     makes, networks.py): ``premasked`` — this layer's output is consumed by exactly one operator, which was told so
     (``x_act``) and returns the gradient already multiplied by act'(y); ``x_act`` — x is such an output."""
-    _need_gpu(x, x2, w, bias)
+    _need_act(x, x2)
+    _need_gpu(w, bias)
     if premasked and (up_out or act == ACT_NONE):
         raise ValueError("conv2d: premasked needs an activated, not upsampled output")
     return _Conv2dFn.apply(x, x2, w, bias, bool(up1), int(stride), int(dil), tuple(int(p) for p in pad), int(act),
-                           bool(up_out), int(dtype), int(x_act), bool(premasked))
+                           bool(up_out), int(dtype), int(x_act), bool(premasked), bool(store16))
 
 
 # ---- U-Net plumbing -----------------------------------------------------------------------------
@@ -324,7 +413,7 @@ class _ShiftMaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, shift, x_act):
         x = x.contiguous()
-        _need_gpu(x)
+        _need_act(x)
         if x.shape[2] % 2 or x.shape[3] % 2:
             raise ValueError("shift_maxpool2: odd spatial size %dx%d" % (x.shape[2], x.shape[3]))
         ctx.shift, ctx.x_act = shift, x_act
@@ -365,7 +454,7 @@ class _UnrotFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, d):
         d = d.contiguous()
-        _need_gpu(d)
+        _need_act(d)
         if d.shape[2] != d.shape[3] or d.shape[0] % 4:
             raise ValueError("unrot4_shift_concat: bad shape %s" % (tuple(d.shape),))
         return _S.unrot4_shift_concat_fwd(d)

@@ -42,6 +42,27 @@ def _f32(like, shape):
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+# storage types of activation tensors: SPRK_DT_* codes <-> torch dtypes (include/sprk.h: SPRK_IO2 / SPRK_IO3)
+TORCH_OF = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}
+CODE_OF = {v: k for k, v in TORCH_OF.items()}
+
+
+def code(t):
+    c = CODE_OF.get(t.dtype)
+    if c is None:
+        raise _lib.SprkError("activation tensors are float32, bfloat16 or float16 (got %s)" % t.dtype)
+    return c
+
+
+def _alloc(like, shape, c):
+    return torch.empty(shape, dtype=TORCH_OF[c], device=like.device)
+
+
+def _out_code(geom_dtype):
+    """storage type of a convolution call's output tensor: the operand type with SPRK_DT_Y16, else fp32"""
+    return (geom_dtype & 0xff) if (geom_dtype & _lib.DT_Y16) else 0
+
+
 def _register(name, schema, impl, fake):
     _LIB.define(name + schema)
     _LIB.impl(name, impl, "CUDA")
@@ -64,7 +85,7 @@ def _conv2d_fwd(x, x2, w, bias, scale, shift, res, geom, res_off, act, up_out, w
     L = _lib.lib()
     g = ConvGeom(*geom)
     m = 2 if up_out else 1
-    y = _f32(x, (g.N, g.Cout, g.Hout * m, g.Wout * m))
+    y = _alloc(x, (g.N, g.Cout, g.Hout * m, g.Wout * m), _out_code(g.dtype))
     ep = _epilogue(bias, scale, shift, res, res_off, act, up_out)
     if ws is None:
         ws = _ws(L.sprk_conv2d_fwd_ws_bytes(ctypes.byref(g)), x)
@@ -75,7 +96,7 @@ def _conv2d_fwd(x, x2, w, bias, scale, shift, res, geom, res_off, act, up_out, w
 
 def _conv2d_fwd_fake(x, x2, w, bias, scale, shift, res, geom, res_off, act, up_out, ws):
     m = 2 if up_out else 1
-    return x.new_empty((geom[0], geom[6], geom[7] * m, geom[8] * m))
+    return x.new_empty((geom[0], geom[6], geom[7] * m, geom[8] * m), dtype=TORCH_OF[_out_code(geom[15])])
 
 
 _register("conv2d_fwd", "(Tensor x, Tensor? x2, Tensor w, Tensor? bias, Tensor? scale, Tensor? shift, Tensor? res, "
@@ -88,9 +109,12 @@ def _conv2d_bwd_data(gy, w, geom, mask_y, mask_act, ws):
     ws: a caller-owned workspace (prepared weights) or None."""
     L = _lib.lib()
     g = ConvGeom(*geom)
-    gin = _f32(gy, (g.N, g.C1 + g.C2, g.Hin, g.Win))
+    gin = _alloc(gy, (g.N, g.C1 + g.C2, g.Hin, g.Win), _out_code(g.dtype))
     if ws is None:
         ws = _ws(L.sprk_conv2d_bwd_data_ws_bytes(ctypes.byref(g)), gy)
+    if mask_y is not None and mask_y.dtype != gin.dtype:
+        raise _lib.SprkError("conv2d_bwd_data: the mask (%s) must have the storage type of the input gradient (%s)" % (
+            mask_y.dtype, gin.dtype))
     if mask_y is not None and tuple(mask_y.shape) != tuple(gin.shape):
         raise _lib.SprkError("conv2d_bwd_data: mask %s does not match the input gradient %s" % (tuple(mask_y.shape), tuple(gin.shape)))
     check(L.sprk_conv2d_bwd_data_masked(_p(gy), _p(w), _p(gin), ctypes.byref(g), _p(mask_y), int(mask_act) if mask_y is not None else 0,
@@ -100,7 +124,8 @@ def _conv2d_bwd_data(gy, w, geom, mask_y, mask_act, ws):
 
 _register("conv2d_bwd_data", "(Tensor gy, Tensor w, int[] geom, Tensor? mask_y, int mask_act, Tensor? ws) -> Tensor",
           _conv2d_bwd_data,
-          lambda gy, w, geom, mask_y, mask_act, ws: gy.new_empty((geom[0], geom[1] + geom[2], geom[3], geom[4])))
+          lambda gy, w, geom, mask_y, mask_act, ws: gy.new_empty((geom[0], geom[1] + geom[2], geom[3], geom[4]),
+                                                                  dtype=TORCH_OF[_out_code(geom[15])]))
 
 
 def _head1x1_fwd(f, w1, b1, w2, b2, w3, b3):
@@ -196,12 +221,14 @@ def drop_pending(dev):
     _PENDING.pop(dev.index, None)
 
 
-def _act_bwd(gy, y, act, geom4, up2, want_gpre, gbias, defer):
+def _act_bwd(gy, y, act, geom4, up2, want_gpre, gbias, defer, out_code):
     """gpre = gy * act'(y) (2x2-summed first when up2); bias gradient into ``gbias`` when given (defer: its final
-    sum is left to ``reduce_pending``).  Returns gpre (or gy itself when no new tensor is needed)."""
+    sum is left to ``reduce_pending``).  Returns gpre (or gy itself when no new tensor is needed).  out_code: storage
+    type of gpre (SPRK_DT_*; gy, y and gpre may each be fp32 or the 16-bit type)."""
     L = _lib.lib()
     N, C, H, W = geom4
-    gpre = _f32(gy, (N, C, H, W)) if want_gpre else None
+    gpre = _alloc(gy, (N, C, H, W), out_code) if want_gpre else None
+    io = code(gy) | ((code(y) if y is not None else 0) << 4) | ((out_code if want_gpre else code(gy)) << 8)
     # gy may be a channel slice of a wider tensor (dense planes, a larger stride between images): read in place
     gstride = 0
     if not gy.is_contiguous():
@@ -213,17 +240,19 @@ def _act_bwd(gy, y, act, geom4, up2, want_gpre, gbias, defer):
     ws = _ws(nb, gy)
     if defer and gbias is not None:
         item = _lib.ReduceItem()
-        check(L.sprk_act_bwd_partial(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, gstride, _p(ws), nb,
+        check(L.sprk_act_bwd_partial(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, gstride, io, _p(ws), nb,
                                      ctypes.byref(item), _stream(gy)), "sprk_act_bwd_partial")
         _pend(gy.device, item, ws)
     else:
-        check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, gstride, _p(ws), nb, _stream(gy)),
+        check(L.sprk_act_bwd(_p(gy), _p(y), _p(gpre), _p(gbias), act, N, C, H, W, up2, gstride, io, _p(ws), nb, _stream(gy)),
               "sprk_act_bwd")
     return gpre if want_gpre else gy.new_empty(0)
 
 
-_register("act_bwd", "(Tensor gy, Tensor? y, int act, int[] nchw, int up2, bool want_gpre, Tensor(a!)? gbias, bool defer) -> Tensor",
-          _act_bwd, lambda gy, y, act, nchw, up2, want_gpre, gbias, defer: gy.new_empty(tuple(nchw) if want_gpre else (0,)))
+_register("act_bwd", "(Tensor gy, Tensor? y, int act, int[] nchw, int up2, bool want_gpre, Tensor(a!)? gbias, bool defer, "
+                     "int out_code) -> Tensor", _act_bwd,
+          lambda gy, y, act, nchw, up2, want_gpre, gbias, defer, out_code: gy.new_empty(
+              tuple(nchw) if want_gpre else (0,), dtype=TORCH_OF[out_code] if want_gpre else gy.dtype))
 
 
 def _concat_up_bwd(gin, C1, C2, up1, x_shape, x2_shape):
@@ -252,24 +281,38 @@ def _simple(name, schema, cfn, out_shape, args):
     _register(name, schema, impl, lambda *a: [t for t in a if torch.is_tensor(t)][0].new_empty(out_shape(*a)))
 
 
-_simple("shift_maxpool2_fwd", "(Tensor x, int shift) -> Tensor", "sprk_shift_maxpool2_fwd",
-        lambda x, shift: (x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2),
-        lambda a, y: (_p(a[0]), _p(y), a[0].shape[0] * a[0].shape[1], a[0].shape[2], a[0].shape[3], a[1]))
-_simple("shift_maxpool2_bwd", "(Tensor gy, Tensor x, int shift, int act) -> Tensor", "sprk_shift_maxpool2_bwd",
-        lambda gy, x, shift, act: tuple(x.shape),
-        lambda a, y: (_p(a[0]), _p(a[1]), _p(y), a[1].shape[0] * a[1].shape[1], a[1].shape[2], a[1].shape[3], a[2], a[3]))
+def _typed(name, schema, cfn, out_shape, out_dtype, args):
+    """Like _simple for the operators whose tensors may be fp32 or 16-bit: out_dtype(*a) -> torch dtype of the output,
+    args(a, y) -> C arguments incl. the io word."""
+    def impl(*a):
+        L = _lib.lib()
+        tensors = [t for t in a if torch.is_tensor(t)]
+        y = torch.empty(out_shape(*a), dtype=out_dtype(*a), device=tensors[0].device)
+        check(getattr(L, cfn)(*args(a, y), _stream(tensors[0])), cfn)
+        return y
+    _register(name, schema, impl, lambda *a: [t for t in a if torch.is_tensor(t)][0].new_empty(out_shape(*a), dtype=out_dtype(*a)))
+
+
+_typed("shift_maxpool2_fwd", "(Tensor x, int shift) -> Tensor", "sprk_shift_maxpool2_fwd",
+       lambda x, shift: (x.shape[0], x.shape[1], x.shape[2] // 2, x.shape[3] // 2), lambda x, shift: x.dtype,
+       lambda a, y: (_p(a[0]), _p(y), a[0].shape[0] * a[0].shape[1], a[0].shape[2], a[0].shape[3], a[1],
+                     code(a[0]) | (code(y) << 4)))
+_typed("shift_maxpool2_bwd", "(Tensor gy, Tensor x, int shift, int act) -> Tensor", "sprk_shift_maxpool2_bwd",
+       lambda gy, x, shift, act: tuple(x.shape), lambda gy, x, shift, act: x.dtype,
+       lambda a, y: (_p(a[0]), _p(a[1]), _p(y), a[1].shape[0] * a[1].shape[1], a[1].shape[2], a[1].shape[3], a[2], a[3],
+                     code(a[0]) | (code(a[1]) << 4) | (code(y) << 8)))
 _simple("rot4_stack_fwd", "(Tensor x) -> Tensor", "sprk_rot4_stack_fwd",
         lambda x: (4 * x.shape[0], x.shape[1], x.shape[2], x.shape[3]),
         lambda a, y: (_p(a[0]), _p(y), a[0].shape[0], a[0].shape[1], a[0].shape[2]))
 _simple("rot4_stack_bwd", "(Tensor gy) -> Tensor", "sprk_rot4_stack_bwd",
         lambda gy: (gy.shape[0] // 4, gy.shape[1], gy.shape[2], gy.shape[3]),
         lambda a, y: (_p(a[0]), _p(y), a[0].shape[0] // 4, a[0].shape[1], a[0].shape[2]))
-_simple("unrot4_shift_concat_fwd", "(Tensor d) -> Tensor", "sprk_unrot4_shift_concat_fwd",
-        lambda d: (d.shape[0] // 4, 4 * d.shape[1], d.shape[2], d.shape[3]),
-        lambda a, y: (_p(a[0]), _p(y), a[0].shape[0] // 4, a[0].shape[1], a[0].shape[2]))
-_simple("unrot4_shift_concat_bwd", "(Tensor gf) -> Tensor", "sprk_unrot4_shift_concat_bwd",
-        lambda gf: (4 * gf.shape[0], gf.shape[1] // 4, gf.shape[2], gf.shape[3]),
-        lambda a, y: (_p(a[0]), _p(y), a[0].shape[0], a[0].shape[1] // 4, a[0].shape[2]))
+_typed("unrot4_shift_concat_fwd", "(Tensor d) -> Tensor", "sprk_unrot4_shift_concat_fwd",
+       lambda d: (d.shape[0] // 4, 4 * d.shape[1], d.shape[2], d.shape[3]), lambda d: d.dtype,
+       lambda a, y: (_p(a[0]), _p(y), a[0].shape[0] // 4, a[0].shape[1], a[0].shape[2], code(a[0]) | (code(y) << 4)))
+_typed("unrot4_shift_concat_bwd", "(Tensor gf) -> Tensor", "sprk_unrot4_shift_concat_bwd",
+       lambda gf: (4 * gf.shape[0], gf.shape[1] // 4, gf.shape[2], gf.shape[3]), lambda gf: gf.dtype,
+       lambda a, y: (_p(a[0]), _p(y), a[0].shape[0], a[0].shape[1] // 4, a[0].shape[2], code(a[0]) | (code(y) << 4)))
 
 # ---- per-pixel pipeline maths ----------------------------------------------------------------------------------------------
 _simple("reparam_fwd", "(Tensor out_stats, Tensor eps) -> Tensor", "sprk_reparam_fwd",

