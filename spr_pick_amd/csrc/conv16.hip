@@ -345,32 +345,66 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
             voff2[r] = ok ? (hil[r] * a.C2 * HW + pix) * ES : (int)0x80000000;
         }
     };
-    unsigned f[R][8];
-    auto fetch = [&](int c0) {      // channels c0 .. c0+15 of the concatenated input -> registers
+    // Register sets of fetched chunks: DEPTH chunks ahead of the one being multiplied.  DEPTH = 2 (16-bit input only: 16
+    // registers per set) was built to keep ~44 KB per CU in flight instead of 22 KB — together with the LDS-only barrier
+    // below, which does not drain the prefetch — and MEASURED: 120.3 -> 125.3 us on the 96 -> 96 layer of the bf16 step
+    // (gpurun_out/p16_a vs p16_d).  The phase experiment (scratch/r4/c16bench.py, SPRK_C16_DIAG) says why: the input
+    // loads are 21 us of 139; the MFMA loop with its LDS operand reads is 62 (38 at the matrix peak), the stores 37, and
+    // the phases of a tile add up instead of overlapping (one workgroup per CU).  So: one set.
+    constexpr int DEPTH = 1;
+    unsigned fA[R][8], fB[DEPTH == 2 ? R : 1][8];
+    auto fetch = [&](int c0, unsigned (&f)[R][8]) {      // channels c0 .. c0+15 of the concatenated input -> registers
         // buffer bases at the chunk's first channel of each source: the per-channel scalar offset stays small
-        // whatever the plane size (4096^2 planes: 64 MB per channel)
+        // whatever the plane size (4096^2 planes: 64 MB per channel).
+        // EVERY path issues exactly R * 8 (or twice that) loads, unconditionally and without per-load vector selects: the
+        // compiler's wait-count pass then knows how many operations are younger than a held register set or the weight
+        // DMA, and waits for those with a non-zero count (a conditional load makes it drain the queue: vmcnt(0)).
+        // A thread without an item carries the out-of-range offset (the load returns 0); channels past the end of the
+        // last chunk re-read the last plane (their weights are zero).
+#ifdef SPRK_DIAG
+        if (k.diag & 1) return;
+#endif
         const int b1 = min(c0, a.C1), b2 = max(c0 - a.C1, 0);
         const char *x1 = reinterpret_cast<const char *>(a.x), *x2 = reinterpret_cast<const char *>(a.x2);
         const rsrc_t r1 = make_rsrc(x1 + ((long)n0 * a.C1 + b1) * HW * ES);
         const rsrc_t r2 = make_rsrc(a.C2 ? x2 + ((long)n0 * a.C2 + b2) * HW * ES : x1);
+        if (a.C2 == 0 || c0 + kTileCK <= a.C1) {          // the whole chunk comes from the first source
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int cg = __builtin_amdgcn_readfirstlane((tid + r * kTileThreads) / P64);
+            for (int r = 0; r < R; ++r) {
+                const int cg = min(__builtin_amdgcn_readfirstlane((tid + r * kTileThreads) / P64), 1);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int ch = c0 + cg * 8 + j;     // wave-uniform
-                unsigned v = 0;
-                if (cg < 2 && ch < Cin && !(k.diag & 1)) {
-                    if (ch < a.C1)
-                        v = __builtin_amdgcn_raw_buffer_load_b32(r1, voff1[r], (ch - b1) * HW * ES, 0);
-                    else
-                        v = __builtin_amdgcn_raw_buffer_load_b32(r2, voff2[r], (ch - a.C1 - b2) * HW * ES, 0);
+                for (int j = 0; j < 8; ++j) {
+                    const int ch = min(c0 + cg * 8 + j, a.C1 - 1);     // wave-uniform
+                    f[r][j] = __builtin_amdgcn_raw_buffer_load_b32(r1, voff1[r], (ch - b1) * HW * ES, 0);
                 }
-                f[r][j] = v;
+            }
+        } else if (c0 >= a.C1) {                          // ... from the second
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int cg = min(__builtin_amdgcn_readfirstlane((tid + r * kTileThreads) / P64), 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ch = min(c0 + cg * 8 + j, Cin - 1);
+                    f[r][j] = __builtin_amdgcn_raw_buffer_load_b32(r2, voff2[r], (ch - a.C1 - b2) * HW * ES, 0);
+                }
+            }
+        } else {                                          // the chunk straddles the sources: one load from each, one of
+            const rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(x1), 0, 0, 0x00020000);   // them from an
+#pragma unroll                                                                                              // empty buffer
+            for (int r = 0; r < R; ++r) {
+                const int cg = min(__builtin_amdgcn_readfirstlane((tid + r * kTileThreads) / P64), 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ch = min(c0 + cg * 8 + j, Cin - 1);
+                    const bool s1 = ch < a.C1;
+                    const unsigned va = __builtin_amdgcn_raw_buffer_load_b32(s1 ? r1 : rz, voff1[r], s1 ? (ch - b1) * HW * ES : 0, 0);
+                    const unsigned vb = __builtin_amdgcn_raw_buffer_load_b32(s1 ? rz : r2, voff2[r], s1 ? 0 : (ch - a.C1 - b2) * HW * ES, 0);
+                    f[r][j] = va | vb;
+                }
             }
         }
     };
-    auto convert_store = [&](int b) {   // registers -> 16 bit -> LDS stage b, [group][pixel][8]
+    auto convert_store = [&](int b, const unsigned (&f)[R][8]) {   // registers -> 16 bit -> LDS stage b, [group][pixel][8]
         const int base = stage0 + b * stageBytes;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -456,53 +490,76 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
     // share the memory system instead of taking turns.
     int tile = xcd_slot(blockIdx.x, gridDim.x, a.xcdRemap);   // gridDim.x <= ntiles: the slot is a valid tile
     if (tile >= ntiles) return;
+    f32x4 acc[MT][NT];
+    auto mma_chunk = [&](int ci) {
+        if (k.diag & 4) return;
+        const bool lastc = ci + 1 >= k.nchunks;
+        const int nks = ((lastc ? k.ngLast : k.ngFull) + 3) >> 2;
+        const int sb = (ci & 1) * stageBytes;
+        const int gaddr = lds_addr(gtab + (lastc ? k.G4 : 0) + lq);
+        const int ain = stage0 + sb, bb0 = baddr0 + sb;
+        for (int ks = 0; ks < nks; ++ks) {
+            const int goff = lds_i(gaddr)[ks * 4] + ain;
+            V8 av[MT], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(abase[mt] + goff);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(bb0 + ks * bstep + nt * 256);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Op16<T>::mma(av[mt], bv[nt], acc[mt][nt]);
+        }
+    };
+    // one chunk: `held` carries chunk ci + 1 (fetched one or two steps ago) and is written to the other LDS stage at the
+    // end; `into` receives the chunk DEPTH steps ahead.  The weight DMA is issued BEFORE the register loads: vmcnt counts
+    // in order, so waiting for the DMA (and for `held`) at the end of the step does not wait for the loads issued after it.
+    auto step = [&](int ci, unsigned (&held)[R][8], unsigned (&into)[R][8]) {
+        // stage ci&1 complete — every wave's ds_writes (lgkmcnt, drained by the barrier) and its share of the weight DMA:
+        // issued a step ago in front of R * 8 register loads, so "at most R * 8 operations outstanding" means it has
+        // landed while those loads (the chunk DEPTH - 1 steps ahead) stay in flight across the barrier
+        if (DEPTH == 2 && ci + DEPTH - 1 < k.nchunks)     // (every wave issues all R * 8 loads of a fetch)
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_only_barrier();     // (the other stage is free again)
+        if (ci + 1 < k.nchunks) weights(ci + 1, (ci + 1) & 1);
+        if (ci + DEPTH < k.nchunks) fetch((ci + DEPTH) * kTileCK, into);
+        mma_chunk(ci);
+        if (ci + 1 < k.nchunks) convert_store((ci + 1) & 1, held);   // waits for `held` (vmcnt), converts, writes the stage
+    };
     setup(tile);
-    fetch(0);
+    fetch(0, fA);
     weights(0, 0);
-    convert_store(0);
+    if constexpr (DEPTH == 2) {
+        if (k.nchunks > 1) fetch(kTileCK, fB);
+    }
+    convert_store(0, fA);
     for (;;) {
-        f32x4 acc[MT][NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ci = 0; ci < k.nchunks; ++ci) {
-            __syncthreads();     // stage ci&1 complete (every wave's ds_writes and DMA); the other stage is free again
-            const bool more = ci + 1 < k.nchunks;
-            if (more) {
-                fetch((ci + 1) * kTileCK);          // in flight while this chunk is multiplied
-                weights(ci + 1, (ci + 1) & 1);
+        if constexpr (DEPTH == 2) {
+            for (int ci = 0; ci < k.nchunks; ci += 2) {      // even chunks live in fA, odd ones in fB
+                step(ci, fB, fA);
+                if (ci + 1 < k.nchunks) step(ci + 1, fA, fB);
             }
-            if (!(k.diag & 4)) {
-                const bool lastc = !more;
-                const int nks = ((lastc ? k.ngLast : k.ngFull) + 3) >> 2;
-                const int sb = (ci & 1) * stageBytes;
-                const int gaddr = lds_addr(gtab + (lastc ? k.G4 : 0) + lq);
-                const int ain = stage0 + sb, bb0 = baddr0 + sb;
-                for (int ks = 0; ks < nks; ++ks) {
-                    const int goff = lds_i(gaddr)[ks * 4] + ain;
-                    V8 av[MT], bv[NT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) av[mt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(abase[mt] + goff);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[nt] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(bb0 + ks * bstep + nt * 256);
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = Op16<T>::mma(av[mt], bv[nt], acc[mt][nt]);
-                }
-            }
-            if (more) convert_store((ci + 1) & 1);   // waits for the fetch (vmcnt), converts, writes the other stage
+        } else {
+            for (int ci = 0; ci < k.nchunks; ++ci) step(ci, fA, fA);
         }
         // ---- this tile's output coordinates, then the next tile's first loads, then the stores --------------------------
         const int e_n0 = n0, e_oy0 = oy0, e_ox0 = ox0;
         const int next = tile + (int)gridDim.x;
         const bool more_tiles = next < ntiles;
-        __syncthreads();                                 // every wave has finished reading the stages
+        lds_only_barrier();                              // every wave has finished reading the stages
         if (more_tiles) {
             setup(next);
-            fetch(0);
+            fetch(0, fA);
             weights(0, 0);
+            if constexpr (DEPTH == 2) {
+                if (k.nchunks > 1) fetch(kTileCK, fB);
+            }
         }
         if (!(k.diag & 8)) {
             // D layout: col(n) = lane & 15 -> output channel, row(m) = (lane >> 4) * 4 + reg -> 4 consecutive pixels
@@ -561,7 +618,7 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
             }
         }
         if (!more_tiles) break;
-        convert_store(0);
+        convert_store(0, fA);
         tile = next;
     }
 }
@@ -616,22 +673,23 @@ __global__ __launch_bounds__(512) void conv16_head_kernel(const Head16Args a) {
         voff[r] = ok ? (p0 + fpx[r]) * ES : (int)0x80000000;
         if (i >= ITEMS) fgrp[r] = -1;
     }
-    unsigned f[R][8];
-    auto fetch = [&](int chunk) {
+    // register sets of fetched chunks: two for 16-bit input (the chunk after next is in flight too: 168 -> 162 us on
+    // 384 -> 384 at 32 x 64^2 in the bf16 step), see conv16_tile_kernel
+    constexpr int DEPTH = X16 ? 2 : 1;
+    unsigned fA[R][8], fB[DEPTH == 2 ? R : 1][8];
+    auto fetch = [&](int chunk, unsigned (&f)[R][8]) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             // buffer based at the 8-channel group (wave-uniform): the scalar channel offset stays below 2^31 on 4096^2 planes
-            const int ch0 = chunk * CK + fgrp[r] * 8;
+            const int ch0 = chunk * CK + max(fgrp[r], 0) * 8;
             const rsrc_t rx = make_rsrc(reinterpret_cast<const char *>(a.x) + ((long)n * a.Cin + ch0) * a.HW * ES);
+            // unconditional, straight-line loads (see conv16_tile_kernel's fetch): a thread without an item carries the
+            // out-of-range offset; Cin is a multiple of CK, so every channel exists
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                unsigned v = 0;
-                if (fgrp[r] >= 0 && ch0 + j < a.Cin) v = __builtin_amdgcn_raw_buffer_load_b32(rx, voff[r], j * a.HW * ES, 0);
-                f[r][j] = v;
-            }
+            for (int j = 0; j < 8; ++j) f[r][j] = __builtin_amdgcn_raw_buffer_load_b32(rx, voff[r], j * a.HW * ES, 0);
         }
     };
-    auto convert_store = [&](int b) {
+    auto convert_store = [&](int b, const unsigned (&f)[R][8]) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if (fgrp[r] < 0) continue;
@@ -669,16 +727,16 @@ __global__ __launch_bounds__(512) void conv16_head_kernel(const Head16Args a) {
     // A: [group][pixel][8]: lane (pixel l15 of tile mt, quarter lq -> group 4 ks + lq);  B: [group][cout][8]
     const int abase = lds0 + (lq * PXT + pg * 64 + l15) * 16;
     const int bbase = lds0 + inBytes + (lq * COUTP + cq * 96 + l15) * 16;
-    fetch(0);
-    weights(0, 0);
-    convert_store(0);
-    for (int c = 0; c < a.nchunks; ++c) {
-        __syncthreads();
-        const bool more = c + 1 < a.nchunks;
-        if (more) {
-            fetch(c + 1);
-            weights(c + 1, (c + 1) & 1);
-        }
+    // one chunk (conv16_tile_kernel's step): weight DMA of the next chunk first, then the register loads DEPTH chunks
+    // ahead; the barrier drains LDS traffic and waits for the DMA only (vmcnt counts in order: R * 8 loads behind it)
+    auto step = [&](int c, unsigned (&held)[R][8], unsigned (&into)[R][8]) {
+        if (DEPTH == 2 && c + DEPTH - 1 < a.nchunks)     // (every wave issues all R * 8 loads of a fetch)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R * 8) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_only_barrier();
+        if (c + 1 < a.nchunks) weights(c + 1, (c + 1) & 1);
+        if (c + DEPTH < a.nchunks) fetch(c + DEPTH, into);
         const int sb = (c & 1) * stageBytes;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
@@ -694,7 +752,21 @@ __global__ __launch_bounds__(512) void conv16_head_kernel(const Head16Args a) {
 #pragma unroll
                 for (int nt = 0; nt < 6; ++nt) acc[mt][nt] = Op16<T>::mma(av[mt], bv[nt], acc[mt][nt]);
         }
-        if (more) convert_store((c + 1) & 1);
+        if (c + 1 < a.nchunks) convert_store((c + 1) & 1, held);
+    };
+    fetch(0, fA);
+    weights(0, 0);
+    if constexpr (DEPTH == 2) {
+        if (a.nchunks > 1) fetch(1, fB);
+    }
+    convert_store(0, fA);
+    if constexpr (DEPTH == 2) {
+        for (int c = 0; c < a.nchunks; c += 2) {
+            step(c, fB, fA);
+            if (c + 1 < a.nchunks) step(c + 1, fA, fB);
+        }
+    } else {
+        for (int c = 0; c < a.nchunks; ++c) step(c, fA, fA);
     }
     // epilogue: D layout col(n) = lane & 15 -> output channel, row(m) = (lane >> 4) * 4 + reg -> 4 consecutive pixels
     // (per-channel constants first, all of them: a load between stores would wait for every store before it)

@@ -23,6 +23,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence + barrier and drains EVERY outstanding
+// vector memory operation first (s_waitcnt vmcnt(0)): register prefetches that are meant to stay in flight across the
+// barrier would be waited for at each one.  Here only lgkmcnt (ds_read / ds_write) is drained; a kernel that stages
+// through LDS-DMA (counted by vmcnt) adds the s_waitcnt vmcnt(n) it needs itself, n = the vector memory operations it
+// issued AFTER that DMA (vmcnt counts in order).
+__device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------
 // LDS-DMA staging (global_load_lds: HBM/L2 -> LDS without passing through VGPRs)
 // ------------------------------------------------------------------------------------------

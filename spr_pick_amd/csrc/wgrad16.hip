@@ -69,7 +69,13 @@ struct Wg16Args {
 // The x tile is a ROLLING window of SLOTS = 2 RH + 2 tile rows per channel: consecutive regions of a strip share RH + 2
 // - RH = 2 halo rows... precisely: region j reads tile rows j RH .. j RH + RH + 1 and only the RH rows below are new, so
 // x is fetched once (the first version re-fetched the halo rows of every region: 2x the bytes at 2-row regions).
-template <typename T, int MC, int LGRW, bool X16>   // MC: output-channel tiles (6: 49..96 channels, 3: 33..48)
+// PL1: padL == 1 (every layer of the networks): the B operands of the kx = 0 and kx = 2 taps start one pixel (2 bytes)
+// left / right of a 16-byte boundary.  gfx950's LDS serves such a ds_read_b128, but slowly: with every B read forced onto
+// the boundary the kernel ran in 148 instead of 202 us (96 -> 96 at 128 x 64^2, scratch/r4/c16bench.py).  So the
+// operand is read ALIGNED (the kx = 1 window) plus the one dword next to it, and shifted by a pixel in registers
+// (4 v_alignbit).  The (cin tile, tap) pairs are dealt to the waves so that slot q of EVERY wave is a kx = q tap
+// (compile-time shift); slot 3 takes the three left-over pairs (waves 0-2) and the tail tile (wave 3).
+template <typename T, int MC, int LGRW, bool X16, bool PL1>   // MC: output-channel tiles (6: 49..96 channels, 3: 33..48)
 __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     constexpr int ES = X16 ? 2 : 4;                            // bytes per element of x / gy in HBM
     using V8 = typename OpW<T>::v8;
@@ -153,9 +159,14 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
             xp[i] = (cl * a.xcs + g4 * 8) | ((rloc < RH ? rloc : 15) << 20) | (s1 ? 0 : 1 << 24);
         }
     };
-    fetch_t fg[GYN], fx[XN];
+    // Register sets of fetched regions, DEPTH regions ahead.  DEPTH = 2 (16-bit tensors: half the registers per set) was
+    // built and measured: 249 us either way on 96 -> 96 at 128 x 64^2 (and 8-200 bytes of scratch at 256 VGPRs).  The phase
+    // experiment (scratch/r4/c16bench.py) shows the loads are not the bound: 209 us all told, 195 without them, 87 without
+    // the MFMA loop — its LDS operand reads (the kx-shifted, 16-byte-misaligned B reads among them) are.  So: one set.
+    constexpr int DEPTH = 1;
+    fetch_t fgA[GYN], fxA[XN], fgB[DEPTH == 2 ? GYN : 1], fxB[DEPTH == 2 ? XN : 1];
     // fetch `rows` tile rows starting at tile row t0 (image row y0 + t0) of the strip: rows outside the image are zeros
-    auto fetch_x = [&](const rsrc_t r1, const rsrc_t r2, int y0, int t0, int rows) {
+    auto fetch_x = [&](fetch_t (&fx)[XN], const rsrc_t r1, const rsrc_t r2, int y0, int t0, int rows) {
 #pragma unroll
         for (int i = 0; i < XN; ++i) {
             const int rloc = (xp[i] >> 20) & 15;
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
             }
         }
     };
-    auto store_x = [&](int t0, int rows) {   // tile row t -> slot t mod SLOTS
+    auto store_x = [&](const fetch_t (&fx)[XN], int t0, int rows) {   // tile row t -> slot t mod SLOTS
 #pragma unroll
         for (int i = 0; i < XN; ++i) {
             const int rloc = (xp[i] >> 20) & 15;
@@ -181,12 +192,12 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
                 *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(ldsX + (xp[i] & 0xFFFFF) + slot * (PITCH * 2)) = cvt4(fx[i]);
         }
     };
-    auto fetch_gy = [&](const rsrc_t rg, int org) {
+    auto fetch_gy = [&](fetch_t (&fg)[GYN], const rsrc_t rg, int org) {
 #pragma unroll
         for (int i = 0; i < GYN; ++i)
             fg[i] = load_item(rg, gyco + 16 * i < gyLim ? gyc0 + i * gycStep : (int)0x80000000, org);
     };
-    auto store_gy = [&](int b) {
+    auto store_gy = [&](const fetch_t (&fg)[GYN], int b) {
 #pragma unroll
         for (int i = 0; i < GYN; ++i)
             *(lds_u16x4w)(__SIZE_TYPE__)(unsigned)(ldsGy + b * gyBytes + gyl0 + i * 16 * kGyStride) = cvt4(fg[i]);
@@ -204,15 +215,48 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     // where the lane's pixel group kq sits in row kq >> 1 at column 8 (kq & 1)
     const int kcol = LGRW == 4 ? (kq & 1) * 8 : kq * 8;
     const bool krow1 = LGRW == 4 && (kq >> 1);
-    int blane[NP], bky[NP];   // lane part of the B address (channel, tap column, pixel group) | tap row (wave-uniform)
+    // pair slots of this wave: q = 0..2 -> (cin tile wave / 3, tap row wave % 3, tap column q); q = 3 -> (cin tile 2, tap
+    // row 2, tap column wave) for waves 0..2 (the 27th.. pairs), the tail tile for wave 3, nothing for waves 4..7
+    int blane[NP], bky[NP];   // lane part of the ALIGNED B address (channel, pixel group; tap column kx = padL) | tap row
+    int bshift[NP];           // bytes from there to the tap's own window: (kx - padL) * 2
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-        const int pr = min(wave + 8 * q, 26);
-        const int it = pr / 9, tap = pr - it * 9;
-        const int ky = tap / 3, kx = tap - ky * 3;
+        const int it = q < 3 ? wave / 3 : 2, ky = q < 3 ? wave % 3 : 2, kx = q < 3 ? q : min(wave, 2);
         bky[q] = __builtin_amdgcn_readfirstlane(ky);
-        blane[q] = ldsX + (it * 16 + l15) * a.xcs + (8 + kx - a.padL + kcol) * 2;
+        blane[q] = ldsX + (it * 16 + l15) * a.xcs + (8 + kcol) * 2;
+        // (diag bit 16, diagnostic builds only: every B read 16-byte aligned — what do the kx-shifted reads cost?)
+        bshift[q] = __builtin_amdgcn_readfirstlane((a.diag & 16) ? 0 : (kx - a.padL) * 2);
     }
+    typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) u32x4b *lds_u4p;
+    typedef const __attribute__((address_space(3))) unsigned *lds_u1p;
+    // B operand of a tap whose window starts SH pixels from the aligned one at byte address ba
+    auto read_b = [&](int ba, auto shc) -> V8 {
+        constexpr int SH = decltype(shc)::value;
+        const u32x4b d = *(lds_u4p)(__SIZE_TYPE__)(unsigned)ba;
+        if constexpr (SH == 0) {
+            return __builtin_bit_cast(V8, d);
+        } else if constexpr (SH < 0) {
+            const unsigned e = *(lds_u1p)(__SIZE_TYPE__)(unsigned)(ba - 4);
+            u32x4b r;
+            r[0] = __builtin_amdgcn_alignbit(d[0], e, 16);
+            r[1] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+            r[2] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+            r[3] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+            return __builtin_bit_cast(V8, r);
+        } else {
+            const unsigned e = *(lds_u1p)(__SIZE_TYPE__)(unsigned)(ba + 16);
+            u32x4b r;
+            r[0] = __builtin_amdgcn_alignbit(d[1], d[0], 16);
+            r[1] = __builtin_amdgcn_alignbit(d[2], d[1], 16);
+            r[2] = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+            r[3] = __builtin_amdgcn_alignbit(e, d[3], 16);
+            return __builtin_bit_cast(V8, r);
+        }
+    };
+    using ICm1 = std::integral_constant<int, -1>;
+    using IC0 = std::integral_constant<int, 0>;
+    using ICp1 = std::integral_constant<int, 1>;
     const int alane = ldsGy + l15 * kGyStride + kq * 16;
     // tail tile: lane's tap = min(l & 15, 8) (columns 9..15 of D are not stored)
     const int ttap = min(l15, 8), tky = ttap / 3, tkx = ttap - tky * 3;
@@ -230,20 +274,28 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
         const rsrc_t rg = make_rsrc(gyb + (long)n * a.Cout * HW * ES);
         const rsrc_t r1 = make_rsrc(xb + (long)n * a.C1 * HW * ES);
         const rsrc_t r2 = make_rsrc(a.C2 ? x2b + (long)n * a.C2 * HW * ES : xb);
-        __syncthreads();                                   // the previous unit's last region has been consumed
-        // prologue: the two halo rows on top, then region 0's RH rows and its gy tile
-        fetch_x(r1, r2, y0, 0, 2);
-        store_x(0, 2);
-        fetch_x(r1, r2, y0, 2, RH);
-        fetch_gy(rg, ((ry0 * RH) * a.W + c0) * ES);
-        store_x(2, RH);
-        store_gy(0);
-        for (int j = 0; j < nreg; ++j) {
-            __syncthreads();                               // region j's tiles are complete; the older ones are free
-            const bool more = j + 1 < nreg;
-            if (more) {                                    // next region: in flight under this region's MFMAs
-                fetch_x(r1, r2, y0, 2 + (j + 1) * RH, RH);
-                fetch_gy(rg, (((ry0 + j + 1) * RH) * a.W + c0) * ES);
+        lds_only_barrier();                                // the previous unit's last region has been consumed
+        auto gy_org = [&](int j) { return (((ry0 + j) * RH) * a.W + c0) * ES; };
+        // prologue: the two halo rows on top, then region 0's RH rows and its gy tile (and region 1 on its way)
+        fetch_x(fxA, r1, r2, y0, 0, 2);
+        store_x(fxA, 0, 2);
+        fetch_x(fxA, r1, r2, y0, 2, RH);
+        fetch_gy(fgA, rg, gy_org(0));
+        if constexpr (DEPTH == 2) {
+            if (nreg > 1) {
+                fetch_x(fxB, r1, r2, y0, 2 + RH, RH);
+                fetch_gy(fgB, rg, gy_org(1));
+            }
+        }
+        store_x(fxA, 2, RH);
+        store_gy(fgA, 0);
+        // region j: `hx / hg` hold region j + 1 (written to LDS at the end), `ix / ig` receive region j + DEPTH
+        auto region = [&](int j, fetch_t (&hx)[XN], fetch_t (&hg)[GYN], fetch_t (&ix)[XN], fetch_t (&ig)[GYN]) {
+            lds_only_barrier();                            // region j's tiles are complete; the older ones are free
+                                                           // (LDS only: the register prefetch stays in flight)
+            if (j + DEPTH < nreg) {                        // in flight under this region's (and the next one's) MFMAs
+                fetch_x(ix, r1, r2, y0, 2 + (j + DEPTH) * RH, RH);
+                fetch_gy(ig, rg, gy_org(j + DEPTH));
             }
             if (!(a.diag & 4)) {
                 const int ga = alane + (j & 1) * gyBytes;
@@ -257,8 +309,6 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
                 }
 #pragma unroll
                 for (int ks = 0; ks < kRegionPx / 32; ++ks) {
-                    constexpr int dummy = 0;
-                    (void)dummy;
                     const int rr = (ks * 32) >> LGRW;                     // region row of this k-step (compile time)
                     const int cc2 = ((ks * 32) & (RW - 1)) * 2;           // byte offset of its first column
                     V8 av[MC], bv[NP];
@@ -274,15 +324,24 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
                             const int so1 = bky[q] == 0 ? srow[rr + 1] : bky[q] == 1 ? srow[rr + 2] : srow[rr + 3];
                             so = krow1 ? so1 : so;
                         }
-                        int ba = blane[q] + so + cc2;
-                        if (q == NP - 1 && tailWave) {                    // wave-uniform: per-lane tap row
+                        const int ba = blane[q] + so + cc2;               // the aligned (kx = padL) window
+                        if (q == NP - 1 && tailWave) {                    // wave-uniform: per-lane tap row and column
                             int t0 = srow[rr], t1 = srow[rr + 1], t2 = srow[rr + 2];
                             if constexpr (LGRW == 4) {
                                 if (krow1) t0 = srow[rr + 1], t1 = srow[rr + 2], t2 = srow[rr + 3];
                             }
-                            ba = tlane + cc2 + (tky == 0 ? t0 : tky == 1 ? t1 : t2);
+                            bv[q] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(tlane + cc2 + (tky == 0 ? t0 : tky == 1 ? t1 : t2));
+                        } else if constexpr (!PL1) {
+                            bv[q] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)(ba + bshift[q]);       // any padL: the direct read
+                        } else if (q == 0) {
+                            bv[q] = read_b(ba, ICm1{});
+                        } else if (q == 1) {
+                            bv[q] = read_b(ba, IC0{});
+                        } else if (q == 2) {
+                            bv[q] = read_b(ba, ICp1{});
+                        } else {                                          // slot 3: the wave's own tap column
+                            bv[q] = bshift[q] < 0 ? read_b(ba, ICm1{}) : bshift[q] == 0 ? read_b(ba, IC0{}) : read_b(ba, ICp1{});
                         }
-                        bv[q] = *(lds_v8p)(__SIZE_TYPE__)(unsigned)ba;
                     }
 #pragma unroll
                     for (int m = 0; m < MC; ++m)
@@ -290,10 +349,18 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
                         for (int q = 0; q < NP; ++q) acc[m][q] = OpW<T>::mma(av[m], bv[q], acc[m][q]);
                 }
             }
-            if (more) {
-                store_x(2 + (j + 1) * RH, RH);
-                store_gy((j + 1) & 1);
+            if (j + 1 < nreg) {
+                store_x(hx, 2 + (j + 1) * RH, RH);
+                store_gy(hg, (j + 1) & 1);
             }
+        };
+        if constexpr (DEPTH == 2) {
+            for (int j = 0; j < nreg; j += 2) {            // even regions live in set A, odd ones in set B
+                region(j, fxB, fgB, fxA, fgA);
+                if (j + 1 < nreg) region(j + 1, fxA, fgA, fxB, fgB);
+            }
+        } else {
+            for (int j = 0; j < nreg; ++j) region(j, fxA, fgA, fxA, fgA);
         }
     }
 
@@ -301,8 +368,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
     float *part = a.partial + (long)blockIdx.x * a.Cout * CinTot * 9;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-        const int pr = wave + 8 * q;
-        if (pr == 27 && tailHere) {                  // the tail channel's tile: column = tap
+        if (q == 3 && wave == 3 && tailHere) {       // the tail channel's tile: column = tap
             if (l15 < 9) {
 #pragma unroll
                 for (int m = 0; m < MC; ++m)
@@ -314,8 +380,8 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_kernel(const Wg16Args a) {
             }
             continue;
         }
-        if (pr >= 27) continue;
-        const int it = pr / 9, tap = pr - it * 9;
+        if (q == 3 && wave >= 3) continue;
+        const int it = q < 3 ? wave / 3 : 2, tap = q < 3 ? (wave % 3) * 3 + q : 6 + wave;
         const int ci = cb0 + it * 16 + l15;
         if (it * 16 + l15 >= cbn) continue;
 #pragma unroll
@@ -435,7 +501,7 @@ __global__ __launch_bounds__(kWgThreads) void wgrad16_1x1_kernel(const Wg1Args a
         store(0);
     }
     for (int r = r0; r < r1; ++r) {
-        __syncthreads();                                   // region r's tiles are complete; the other stage is free
+        lds_only_barrier();                                // region r's tiles are complete; the other stage is free
         const int b = (r - r0) & 1;
         const bool more = r + 1 < r1;
         if (more) {
@@ -656,14 +722,15 @@ int wgrad16_run(const Wgrad16Call &c, const void *x, const void *x2, const void 
     };
     auto pick = [&](auto tag) {
         using T = decltype(tag);
-        if (c.x16) {
-            if (p.lgRW == 6) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 6, true>) : go(wgrad16_kernel<T, 3, 6, true>);
-            if (p.lgRW == 5) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 5, true>) : go(wgrad16_kernel<T, 3, 5, true>);
-            return p.MC == 6 ? go(wgrad16_kernel<T, 6, 4, true>) : go(wgrad16_kernel<T, 3, 4, true>);
-        }
-        if (p.lgRW == 6) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 6, false>) : go(wgrad16_kernel<T, 3, 6, false>);
-        if (p.lgRW == 5) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 5, false>) : go(wgrad16_kernel<T, 3, 5, false>);
-        return p.MC == 6 ? go(wgrad16_kernel<T, 6, 4, false>) : go(wgrad16_kernel<T, 3, 4, false>);
+        auto shape = [&](auto x16c, auto pl1c) {
+            constexpr bool X = decltype(x16c)::value, P1 = decltype(pl1c)::value;
+            if (p.lgRW == 6) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 6, X, P1>) : go(wgrad16_kernel<T, 3, 6, X, P1>);
+            if (p.lgRW == 5) return p.MC == 6 ? go(wgrad16_kernel<T, 6, 5, X, P1>) : go(wgrad16_kernel<T, 3, 5, X, P1>);
+            return p.MC == 6 ? go(wgrad16_kernel<T, 6, 4, X, P1>) : go(wgrad16_kernel<T, 3, 4, X, P1>);
+        };
+        const bool pl1 = c.padL == 1;
+        if (c.x16) return pl1 ? shape(std::true_type{}, std::true_type{}) : shape(std::true_type{}, std::false_type{});
+        return pl1 ? shape(std::false_type{}, std::true_type{}) : shape(std::false_type{}, std::false_type{});
     };
     prof_begin(c.kclass, c.flops, s);
     prof_bytes((c.x16 ? 2.0 : 4.0) * c.N * ((double)(c.C1 + c.C2) * c.H * c.W + (double)c.Cout * c.Hout * c.Wout));

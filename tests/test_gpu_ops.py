@@ -318,7 +318,7 @@ def test_shift_maxpool_ties_go_to_the_first_maximum(shape):
     assert torch.equal(xd.grad.cpu(), xr.grad.float())
 
 
-@pytest.mark.parametrize("B,C,P", [(2, 1, 64), (3, 2, 8), (1, 4, 2), (2, 3, 96)])
+@pytest.mark.parametrize("B,C,P", [(2, 1, 64), (3, 2, 8), (1, 4, 2), (2, 3, 96), (1, 3, 128)])
 def test_rot4_and_unrot4(B, C, P):
     from oracle import networks
     from spr_pick_amd import ops
@@ -730,14 +730,15 @@ def test_plumbing_kernels_on_16bit_tensors(dt):
             g16, = torch.autograd.grad(y16, x16, gy.to(d))
             g32, = torch.autograd.grad(y32, x32, gy.float().to(d))
             assert g16.dtype == tdt and torch.equal(g16.float(), g32.to(tdt).float())
-    dd = torch.randn(8, 6, 32, 32, generator=g).to(tdt)
-    d16, d32 = dd.to(d).requires_grad_(True), dd.float().to(d).requires_grad_(True)
-    f16, f32 = ops.unrot4_shift_concat(d16), ops.unrot4_shift_concat(d32)
-    assert f16.dtype == tdt and torch.equal(f16.float(), f32)
-    gf = torch.randn(f32.shape, generator=g).to(tdt)
-    a16, = torch.autograd.grad(f16, d16, gf.to(d))
-    a32, = torch.autograd.grad(f32, d32, gf.float().to(d))
-    assert a16.dtype == tdt and torch.equal(a16.float(), a32)
+    for P in (32, 64, 128):           # the 32x32-tile kernel, the 64x64-tile kernel with one and with four tiles per plane
+        dd = torch.randn(8, 6, P, P, generator=g).to(tdt)
+        d16, d32 = dd.to(d).requires_grad_(True), dd.float().to(d).requires_grad_(True)
+        f16, f32 = ops.unrot4_shift_concat(d16), ops.unrot4_shift_concat(d32)
+        assert f16.dtype == tdt and torch.equal(f16.float(), f32)
+        gf = torch.randn(f32.shape, generator=g).to(tdt)
+        a16, = torch.autograd.grad(f16, d16, gf.to(d))
+        a32, = torch.autograd.grad(f32, d32, gf.float().to(d))
+        assert a16.dtype == tdt and torch.equal(a16.float(), a32)
     # activation backward: gpre = gy * act'(y), bias sums in fp32; every storage combination, dense / upsampled / sliced gy
     S = torch.ops.sprk
     N, C, H, W = 6, 10, 16, 24
