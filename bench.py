@@ -559,9 +559,11 @@ def main():
                   "unit": "patches/s", "steps": k2, "ms_per_step": dt2 / k2 * 1e3,
                   "final_loss": float(torch.mean(o2[P.LOSS].detach())),
                   "conv_layers_requesting_16bit": n16, "conv_launches_on_16bit_kernels_per_step": c16_per_step,
-                  "note": "same step, U-Net MFMA operands rounded to %s in forward, backward-data and backward-weight (fp32 "
-                          "tensors, master weights, accumulation); layers the 16-bit kernels do not cover (1x1 backward-"
-                          "weight, planes below 32x32, the detector, the output convolutions) run fp32" % args.also_dtype}
+                  "note": "same step, %s MFMA operands in forward, backward-data and backward-weight of the U-Nets AND %s "
+                          "activation / activation-gradient tensors between their layers (fp32 master weights, weight "
+                          "gradients, accumulation, optimiser); layers the 16-bit kernels do not cover (planes below 32x32 "
+                          "at this batch, the detector, the output convolutions) run on fp32 tensors" % (
+                              args.also_dtype, args.also_dtype)}
         # roofline of this leg: its dominant kernels are HBM-bound (fp32 tensors in and out, 16x the matrix rate), so
         # they are priced in algorithmic GB/s: three eager steps, the two 16-bit kernel classes bracketed by events
         for kc in (5, 6):
@@ -585,10 +587,35 @@ def main():
                            "frac": by_.value / (ms_.value * 1e-3) / 1e9 / PEAK_HBM_GBS, "bound": "hbm", "traffic": None,
                            "achieved_tflops": fl_.value / (ms_.value * 1e-3) / 1e12, "ms_per_step": ms_.value / 3}
         if r16:
+            # HBM bytes per launch of each class from the committed PMC passes of this command (profiles/collect.sh: separate
+            # FETCH_SIZE / WRITE_SIZE runs with --dtype bf16), used only while the kernel sources are the ones profiled
+            t16, t16_src = {}, "not measured in this run (PMC counters need rocprofv3: profiles/collect.sh)"
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+                try:
+                    with open(path) as f:
+                        tj = json.load(f)
+                    if tj.get("kernel_source_hash") == kernel_source_hash() and tj.get("kernels_bf16_step"):
+                        for kc, pre in ((5, ("conv16_tile_kernel", "conv16_mfma_kernel", "conv16_head_kernel")),
+                                        (6, ("wgrad16_kernel", "wgrad16_1x1_kernel"))):
+                            fam = [v for k, v in tj["kernels_bf16_step"].items() if k.startswith(pre)]
+                            n = sum(v["launches"] for v in fam)
+                            if n:
+                                t16[kc] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam) / n
+                        t16_src = "%s: rocprofv3 PMC passes of bench.py --dtype bf16 on these kernel sources, launch-weighted over the class; not this run" % os.path.relpath(path, ROOT)
+                        break
+                except (OSError, KeyError, ValueError):
+                    pass
+            for kc in r16:
+                r16[kc]["traffic"] = t16.get(kc)
+                r16[kc]["traffic_source"] = t16_src
+                r16[kc]["algorithmic_bytes_per_launch"] = r16[kc]["achieved"] * 1e9 * r16[kc]["avg_launch_ms"] * 1e-3
+                r16[kc]["frac_of_achievable_hbm"] = r16[kc]["achieved"] / 6300.0
             dom16 = max(r16, key=lambda k: r16[k]["ms_per_step"])
-            second["roofline"] = dict(r16[dom16], note="algorithmic bytes = every input and output tensor once, fp32 "
-                                      "(SURVEY 8d formula per launch) / event time of the launches; 6.3 TB/s is what a "
-                                      "copy reaches on this part")
+            second["roofline"] = dict(r16[dom16], note="algorithmic bytes = every activation tensor of a launch once AT ITS "
+                                      "STORAGE TYPE (16-bit tensors between the U-Nets' layers, fp32 at their borders) / event "
+                                      "time of the launches; peak 8 TB/s, 6.3 TB/s is what a copy reaches on this part "
+                                      "(frac_of_achievable_hbm); these kernels are bound by LDS operand reads and the "
+                                      "un-overlapped phases of a tile, not by HBM (DESIGN 4.4: scratch/r4/c16bench.py)")
             second["other_16bit_kernels"] = [v for k, v in r16.items() if k != dom16]
         value_of[args.also_dtype] = second["value"]
         del o2, st2

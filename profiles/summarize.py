@@ -58,7 +58,12 @@ def family(name):
     m = re.match(r"(wino_conv_kernel)<(\d+),", name)   # <NT, tile geometry> -> <NT>
     if m:
         return "%s<%s>" % m.groups()
-    m = re.match(r"(conv16_tile_kernel|conv16_mfma_kernel|wgrad16_kernel)<[^,]+, (\d+)", name)   # <dtype, NT/MT/MC, ...>
+    m = re.match(r"(conv16_mfma_kernel)<[^,]+, (\d+)", name)   # <dtype, MT, ...>
+    if m:
+        return "%s<%s>" % m.groups()
+    # conv16_tile_kernel<T, NT, X16, Y16>, conv16_head_kernel<T, CQ, CK, X16, Y16>, wgrad16_kernel<T, MC, LGRW, X16, PL1>:
+    # the storage variants are different kernels as far as HBM bytes go — kept apart; the operand type is dropped
+    m = re.match(r"(conv16_tile_kernel|conv16_head_kernel|wgrad16_kernel|wgrad16_1x1_kernel)<[^,]+, (.*)>$", name)
     if m:
         return "%s<%s>" % m.groups()
     m = re.match(r"(conv_wgrad_mfma_kernel)<", name)
@@ -120,27 +125,40 @@ def counters(sub):
     return out
 
 
-fetch, write = counters("fetch"), counters("write")
-traffic = {}
-for k in sorted(set(fetch) | set(write)):
-    if not any(t in k for t in ("conv", "wino", "act_bwd", "bn_", "nms", "unrot", "rot4", "maxpool", "head", "adam")):
-        continue      # library kernels only (the stock ATen elementwise kernels are not this repo's)
-    fk = fetch.get(k, {}).get("FETCH_SIZE", [0.0, 1])
-    wk = write.get(k, {}).get("WRITE_SIZE", [0.0, 1])
-    fkb, wkb = fk[0] / max(fk[1], 1), wk[0] / max(wk[1], 1)
-    traffic[k] = {"launches": int(max(fk[1], wk[1])), "FETCH_SIZE_KB_avg": fkb, "WRITE_SIZE_KB_avg": wkb,
-                  "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0}
+def traffic_of(fsub, wsub):
+    fetch, write = counters(fsub), counters(wsub)
+    traffic = {}
+    for k in sorted(set(fetch) | set(write)):
+        if not any(t in k for t in ("conv", "wino", "wgrad", "act_bwd", "bn_", "nms", "unrot", "rot4", "maxpool", "head", "adam")):
+            continue      # library kernels only (the stock ATen elementwise kernels are not this repo's)
+        fk = fetch.get(k, {}).get("FETCH_SIZE", [0.0, 1])
+        wk = write.get(k, {}).get("WRITE_SIZE", [0.0, 1])
+        fkb, wkb = fk[0] / max(fk[1], 1), wk[0] / max(wk[1], 1)
+        traffic[k] = {"launches": int(max(fk[1], wk[1])), "FETCH_SIZE_KB_avg": fkb, "WRITE_SIZE_KB_avg": wkb,
+                      "hbm_bytes_per_launch": (2.0 * fkb + wkb) * 1024.0}
+    return traffic
+
+
+traffic = traffic_of("fetch", "write")
+traffic16 = traffic_of("fetch16", "write16") if os.path.isdir(os.path.join(src, "fetch16")) else {}
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_hash  # noqa: E402  (bench.py trusts this file only for the same kernel sources)
 
 json.dump({"kernel_source_hash": kernel_source_hash(),
            "note": "per-launch averages over the profiled bench run; FETCH_SIZE doubled (gfx950 counts 128-B "
                    "requests at 64 B for wide streaming reads), WRITE_SIZE as is; separate PMC passes",
-           "kernels": traffic}, open(os.path.join(here, tag + "_hbm_traffic.json"), "w"), indent=1)
+           "kernels": traffic,
+           "kernels_bf16_step": traffic16,
+           "bf16_note": "kernels_bf16_step: the same passes on bench.py --dtype bf16 (16-bit operands AND 16-bit activation "
+                        "tensors between the U-Nets' layers)"},
+          open(os.path.join(here, tag + "_hbm_traffic.json"), "w"), indent=1)
 
 mf = counters("mfma")
-json.dump({k: {cn: {"sum": v[0], "launches": v[1]} for cn, v in d.items()} for k, d in mf.items()
-           if "conv" in k or "wino" in k}, open(os.path.join(here, tag + "_mfma_counters.json"), "w"), indent=1)
+mfj = {k: {cn: {"sum": v[0], "launches": v[1]} for cn, v in d.items()} for k, d in mf.items() if "conv" in k or "wino" in k}
+if os.path.isdir(os.path.join(src, "mfma16")):
+    mfj["bf16_step"] = {k: {cn: {"sum": v[0], "launches": v[1]} for cn, v in d.items()} for k, d in counters("mfma16").items()
+                        if "conv" in k or "wgrad" in k or "wino" in k}
+json.dump(mfj, open(os.path.join(here, tag + "_mfma_counters.json"), "w"), indent=1)
 for name in ("bench.json", "bench_under_rocprof.json"):
     open(os.path.join(here, "%s_%s" % (tag, name)), "w").write(open(os.path.join(src, name)).read())
 print("wrote summaries for", tag)

@@ -561,7 +561,76 @@ __global__ __launch_bounds__(kTileThreads) void conv16_tile_kernel(const Tile16A
                 if (k.nchunks > 1) fetch(kTileCK, fB);
             }
         }
-        if (!(k.diag & 8)) {
+        // 16-bit output of a tile that lies wholly inside the tensor: through LDS, so that a wave's store instruction
+        // writes whole 128-byte rows of one channel (64 lanes x 16 bytes = the tile's 512 pixels of that channel) instead
+        // of 16 channels x 32 bytes.  The stores were 37 of the kernel's 139 us on 96 -> 96 at 128 x 64^2, un-overlapped
+        // (scratch/r4/c16bench.py).  The transposed tile lives in stage 1 (free until the next tile's first barrier):
+        // [channel][512 pixels] 16 bit, rows of 1040 bytes, PN channel tiles per pass.
+        bool ldsEp = false;
+        if constexpr (Y16) {
+            ldsEp = (a.Wout & 7) == 0 && e_n0 + NI <= a.N && e_oy0 + (TRm + 1) <= a.Hout && e_ox0 + (TCm + 1) <= a.Wout &&
+                    !(k.diag & 8);
+        }
+        if constexpr (Y16) {
+            if (ldsEp) {
+                constexpr int PN = NT == 6 ? 3 : 1, ROWB = 1040, PASSES = NT / PN, UNITS = PN * 16 * 64 / kTileThreads;
+                typedef unsigned u32x2t __attribute__((ext_vector_type(2)));
+                typedef unsigned u32x4t __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(3))) u32x2t *lds_u2w;
+                typedef const __attribute__((address_space(3))) u32x4t *lds_u4r;
+                typedef T t4v __attribute__((ext_vector_type(4)));
+                const int tbase = stage0 + stageBytes;
+                // reader geometry: unit i of this thread = (channel wave + 8 i of the pass, pixels 8 lane .. 8 lane + 7)
+                const int rp = lane * 8;
+                const int ril = rp >> lgT, rr = (rp >> a.lgTC) & TRm, rc = rp & TCm;
+                const long rpix = a.up2 ? (long)(2 * (e_oy0 + rr)) * W2 + 2 * (e_ox0 + rc) : (long)(e_oy0 + rr) * a.Wout + e_ox0 + rc;
+                T *const ybase = reinterpret_cast<T *>(a.y) + (long)(e_n0 + ril) * a.Cout * planeY + rpix;
+#pragma unroll
+                for (int ps = 0; ps < PASSES; ++ps) {
+#pragma unroll
+                    for (int pn = 0; pn < PN; ++pn) {
+                        const int nt = ps * PN + pn;
+                        const float sc = esc[nt], sh = esh[nt];
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const f32x4 c = acc[mt][nt];
+                            t4v o;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = (T)apply_act(c[j] * sc + sh, a.act);
+                            *(lds_u2w)(__SIZE_TYPE__)(unsigned)(tbase + (pn * 16 + l15) * ROWB + ((wave * MT + mt) * 16 + lq * 4) * 2) =
+                                __builtin_bit_cast(u32x2t, o);
+                        }
+                    }
+                    lds_only_barrier();
+#pragma unroll
+                    for (int i = 0; i < UNITS; ++i) {
+                        const int chl = wave + 8 * i;                       // wave-uniform
+                        const int co = nb * NT16 + ps * PN * 16 + chl;
+                        if (co >= a.Cout) continue;
+                        const u32x4t v = *(lds_u4r)(__SIZE_TYPE__)(unsigned)(tbase + chl * ROWB + lane * 16);
+                        T *q = ybase + co * planeY;
+                        if (a.up2) {
+                            u32x4t lo, hi;
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                lo[2 * j] = __builtin_amdgcn_perm(v[j], v[j], 0x01000100u);
+                                lo[2 * j + 1] = __builtin_amdgcn_perm(v[j], v[j], 0x03020302u);
+                                hi[2 * j] = __builtin_amdgcn_perm(v[2 + j], v[2 + j], 0x01000100u);
+                                hi[2 * j + 1] = __builtin_amdgcn_perm(v[2 + j], v[2 + j], 0x03020302u);
+                            }
+                            *reinterpret_cast<u32x4t *>(q) = lo;
+                            *reinterpret_cast<u32x4t *>(q + 8) = hi;
+                            *reinterpret_cast<u32x4t *>(q + W2) = lo;
+                            *reinterpret_cast<u32x4t *>(q + W2 + 8) = hi;
+                        } else {
+                            *reinterpret_cast<u32x4t *>(q) = v;
+                        }
+                    }
+                    if (ps + 1 < PASSES) lds_only_barrier();                // the next pass overwrites the transposed tile
+                }
+            }
+        }
+        if (!(k.diag & 8) && !ldsEp) {
             // D layout: col(n) = lane & 15 -> output channel, row(m) = (lane >> 4) * 4 + reg -> 4 consecutive pixels
             long poff[MT];
 #pragma unroll
