@@ -24,6 +24,20 @@ def db(sub):
     return sqlite3.connect(os.path.join(d, f))
 
 
+def have(sub):
+    return os.path.isdir(os.path.join(src, sub))
+
+
+def mangled_of(con):
+    """display name -> mangled name.  rocprofv3's own demangler garbles kernels with a __bf16 / _Float16 template
+    argument AND further arguments behind it ("conv16_tile_kernel<bool _Accum, int, ELb1EL, bool, E>"): the summaries
+    are keyed by the MANGLED name of the symbol table, demangled here."""
+    try:
+        return {d: m for m, d in con.execute("select kernel_name, display_name from kernel_symbols") if "DF16" in m}
+    except sqlite3.Error:
+        return {}
+
+
 def demangle(name):
     """_ZN12_GLOBAL__N_118conv16_tile_kernelIDF16bLi6EEEvNS_10Tile16ArgsE -> conv16_tile_kernel<bf16, 6> (rocprofv3 leaves the
     kernels with a __bf16 / _Float16 template argument mangled)."""
@@ -35,8 +49,6 @@ def demangle(name):
     rest = name[m.end() + n:]
     args = []
     if rest.startswith("I"):
-        for tok in re.findall(r"DF16b|DF16_|Li(\d+)E|Lb([01])E", rest.split("EEv")[0]):
-            pass
         for mm in re.finditer(r"DF16b|DF16_|Li\d+E|Lb[01]E", rest.split("EEv")[0]):
             t = mm.group(0)
             args.append("bf16" if t == "DF16b" else "f16" if t == "DF16_" else t[2:-1] if t[1] == "i" else ("true" if t[2] == "1" else "false"))
@@ -70,10 +82,25 @@ def family(name):
     return m.group(1) if m else name
 
 
-rows = list(db("trace").execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
-                                "from kernels group by name order by 3 desc"))
+def kernel_rows(sub, cols):
+    con = db(sub)
+    mg = mangled_of(con)
+    agg = collections.OrderedDict()
+    for r in con.execute("select name, end - start from kernels"):
+        n = mg.get(r[0], r[0])
+        e = agg.setdefault(n, [0, 0, 1 << 62, 0])
+        e[0] += 1
+        e[1] += r[1]
+        e[2] = min(e[2], r[1])
+        e[3] = max(e[3], r[1])
+    out = [(n, c, t, t / c, mn, mx) for n, (c, t, mn, mx) in agg.items()]
+    out.sort(key=lambda r: -r[2])
+    return [r[:cols] for r in out]
+
+
+rows = kernel_rows("trace", 6) if have("trace") else []
 total = sum(r[2] for r in rows)
-with open(os.path.join(here, tag + "_bench_kernel_stats.csv"), "w", newline="") as f:
+with open(os.path.join(here, tag + "_bench_kernel_stats.csv"), "w", newline="") if rows else open(os.devnull, "w") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
     for n, c, t, a, mn, mx in rows:
@@ -92,8 +119,7 @@ with open(os.path.join(here, tag + "_bench_kernel_stats.csv"), "w", newline="") 
 
 
 def kernel_csv(sub, name, note):
-    rows = list(db(sub).execute("select name, count(*), sum(end-start), avg(end-start) from kernels group by name "
-                                "order by 3 desc"))
+    rows = kernel_rows(sub, 4)
     total = sum(r[2] for r in rows)
     fam = collections.OrderedDict()
     for n, c, t, a in rows:
@@ -108,18 +134,20 @@ def kernel_csv(sub, name, note):
             w.writerow([k, c, t, "%.1f" % (t / c), "%.3f" % (100.0 * t / total)])
 
 
-if os.path.isdir(os.path.join(src, "trace16")):
+if have("trace16"):
     kernel_csv("trace16", tag + "_bench_bf16_kernel_stats.csv",
                "bench.py --dtype bf16 (U-Net MFMA operands in bf16): kernel trace of 3 warm-up + 10 timed + event steps")
-if os.path.isdir(os.path.join(src, "infer")):
+if have("infer"):
     kernel_csv("infer", tag + "_infer4096_kernel_stats.csv",
                "scratch/infer_prof.py 4096: three filled 4096x4096 inferences + NMS (first one includes warm-up)")
 
 
 def counters(sub):
     out = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-    for k, cn, v in db(sub).execute("select kernel_name, counter_name, value from counters_collection"):
-        e = out[family(short(k))][cn]
+    con = db(sub)
+    mg = mangled_of(con)
+    for k, cn, v in con.execute("select kernel_name, counter_name, value from counters_collection"):
+        e = out[family(short(mg.get(k, k)))][cn]
         e[0] += v
         e[1] += 1
     return out
@@ -139,8 +167,17 @@ def traffic_of(fsub, wsub):
     return traffic
 
 
-traffic = traffic_of("fetch", "write")
-traffic16 = traffic_of("fetch16", "write16") if os.path.isdir(os.path.join(src, "fetch16")) else {}
+def previous(name):
+    try:
+        with open(os.path.join(here, tag + name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+prev_t, prev_m = previous("_hbm_traffic.json"), previous("_mfma_counters.json")
+traffic = traffic_of("fetch", "write") if have("fetch") and have("write") else prev_t.get("kernels", {})
+traffic16 = traffic_of("fetch16", "write16") if have("fetch16") and have("write16") else prev_t.get("kernels_bf16_step", {})
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_hash  # noqa: E402  (bench.py trusts this file only for the same kernel sources)
 
@@ -153,12 +190,18 @@ json.dump({"kernel_source_hash": kernel_source_hash(),
                         "tensors between the U-Nets' layers)"},
           open(os.path.join(here, tag + "_hbm_traffic.json"), "w"), indent=1)
 
-mf = counters("mfma")
-mfj = {k: {cn: {"sum": v[0], "launches": v[1]} for cn, v in d.items()} for k, d in mf.items() if "conv" in k or "wino" in k}
-if os.path.isdir(os.path.join(src, "mfma16")):
+if have("mfma"):
+    mf = counters("mfma")
+    mfj = {k: {cn: {"sum": v[0], "launches": v[1]} for cn, v in d.items()} for k, d in mf.items() if "conv" in k or "wino" in k}
+else:
+    mfj = {k: v for k, v in prev_m.items() if k != "bf16_step"}
+if not have("mfma16") and "bf16_step" in prev_m:
+    mfj["bf16_step"] = prev_m["bf16_step"]
+if have("mfma16"):
     mfj["bf16_step"] = {k: {cn: {"sum": v[0], "launches": v[1]} for cn, v in d.items()} for k, d in counters("mfma16").items()
                         if "conv" in k or "wgrad" in k or "wino" in k}
 json.dump(mfj, open(os.path.join(here, tag + "_mfma_counters.json"), "w"), indent=1)
 for name in ("bench.json", "bench_under_rocprof.json"):
-    open(os.path.join(here, "%s_%s" % (tag, name)), "w").write(open(os.path.join(src, name)).read())
+    if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)):
+        open(os.path.join(here, "%s_%s" % (tag, name)), "w").write(open(os.path.join(src, name)).read())
 print("wrote summaries for", tag)
