@@ -41,7 +41,7 @@ constexpr int kClass16W = 6;  // ... of the 16-bit-operand backward-weight kerne
 //   mode 0 (forward):        GEMM-k channel = cin,  n = cout, tap as is
 //   mode 1 (backward-data):  GEMM-k channel = cout, n = cin,  tap flipped
 // Row order: chunks of CK k-channels; inside a chunk row = tap * cke + cl (cke = channels
-// actually present in the chunk); every chunk occupies R4 = roundup4(CK*KHW) rows.
+// actually present in the chunk); every chunk occupies R4 = roundup(CK*KHW, 4) rows (16 for MT = 1).
 // Each N-block (NT*16 output channels) is stored as its own [rows][ldw] slab with the LDS row
 // stride ldw (zero padded), so a chunk of a slab is one contiguous run that LDS-DMA copies 1:1.
 // The first 256 floats of the workspace are zeroed: the DMA source of out-of-image lanes.
@@ -170,13 +170,89 @@ __device__ __forceinline__ void chunk_mma(f32x4 (&acc)[MT][NT], const int (&abas
     }
 }
 
+// MT = 1, NT <= 3 (planes of a few pixels: the U-Net levels <= 16x16 and the detector's patch layers): one pixel tile per wave
+// means 1..6 MFMAs per k-step, far less than the two LDS round trips (k-row offset -> operand) a step of chunk_mma
+// exposes, and these launches are latency-bound (8..512 workgroups, each alone on its CU).  Here a wave walks the
+// chunk in groups of U k-steps: the offsets of group g+2 and the operands of group g+1 are in flight under the MFMAs
+// of group g (U = 4, or 2 with three cout tiles), and with one or two cout tiles the steps of a group alternate
+// between two accumulator sets (half the dependent-MFMA chain).  nkq is a multiple of U (the plan rounds a chunk's
+// rows to 16: zero weight rows).
+template <int NT>
+__device__ __forceinline__ void chunk_mma_small(f32x4 (&acc)[1][NT], int abase, int kaddr, int baddr, int bstep, int nkq) {
+    static_assert(NT <= 3, "four or more cout tiles: chunk_mma hides the latencies under its MFMAs (measured: this form is slower)");
+    constexpr int U = NT <= 2 ? 4 : 2;
+    constexpr bool TWO = NT <= 2;
+    const int ng = nkq / U, lastg = ng - 1;
+    int ko[U];
+    float av[U], bv[U][NT];
+    f32x4 acc2[TWO ? NT : 1];
+#pragma unroll
+    for (int nt = 0; nt < (TWO ? NT : 1); ++nt) acc2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < U; ++u) ko[u] = lds_i(kaddr)[u * 4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        av[u] = *lds_f(abase + ko[u]);
+        lds_cfp bp = lds_f(baddr + u * bstep);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[u][nt] = bp[16 * nt];
+    }
+    {
+        const int g1 = min(1, lastg);
+#pragma unroll
+        for (int u = 0; u < U; ++u) ko[u] = lds_i(kaddr)[(g1 * U + u) * 4];
+    }
+    for (int g = 0; g < ng; ++g) {
+        const int gn = min(g + 1, lastg), gnn = min(g + 2, lastg);   // the last groups re-read themselves (unused)
+        float an[U], bn[U][NT];
+        int kn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            an[u] = *lds_f(abase + ko[u]);
+            lds_cfp bp = lds_f(baddr + (gn * U + u) * bstep);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bn[u][nt] = bp[16 * nt];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) kn[u] = lds_i(kaddr)[(gnn * U + u) * 4];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (TWO && (u & 1))
+                    acc2[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][nt], acc2[nt], 0, 0, 0);
+                else
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][nt], acc[0][nt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            av[u] = an[u];
+            ko[u] = kn[u];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[u][nt] = bn[u][nt];
+        }
+    }
+    if (TWO) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[0][nt] += acc2[nt];
+    }
+}
+
 // RB: row bases per wave (1: the wave's MT pixel tiles lie in one tile row, ... MT: one base per tile).
 // XTAB: inputs staged by buffer loads through the per-tile offset tables (the normal case); the other
 // instantiation keeps the pointer-arithmetic staging for geometries the tables do not cover (rows that are
 // not 16-byte aligned).  Two kernels instead of a run-time branch: the K-chunk loop is short on scalar
 // registers, and every spilled scalar comes back through a v_readlane, i.e. a VALU instruction.
+#ifdef SPRK_DIAG
+__device__ long long sprk_diag_conv_clk[40];   // phase time stamps of workgroup 0 (wall_clock64: 10 ns units)
+#define SPRK_DIAG_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) sprk_diag_conv_clk[i] = wall_clock64(); } while (0)
+#else
+#define SPRK_DIAG_STAMP(i)
+#endif
+
 template <int MT, int NT, int RB, bool XTAB>
 __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) {
+    SPRK_DIAG_STAMP(0);
     // LDS: koff[2][R4] (full chunk | last chunk) | xtab1[nG1*64] xtab2[nG2*64] | stage 0: input[CK*cplane]
     //      weights[R4*ldw] | stage 1: ...
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -190,6 +266,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     constexpr int TM = 64 * MT;
+    constexpr int kRowUnit = (MT == 1 && NT <= 3) ? 16 : 4;   // a chunk's k rows are rounded to this (plan_fwd: R4)
     const int lgT = a.lgTC + a.lgTR;
     const int NI = TM >> lgT;
     // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
@@ -224,19 +301,6 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // k-row byte offsets (tap-major inside a chunk) for a full chunk and for the last, possibly shorter one
-    const int ckeLast = Cin - ((Cin - 1) / a.CK) * a.CK;
-    for (int idx = tid; idx < 2 * a.R4; idx += kBlock) {
-        const int which = idx >= a.R4, k = idx - which * a.R4;
-        const int cke = which ? ckeLast : a.CK;
-        int v = 0;
-        if (k < cke * KHW) {
-            const int tap = k / cke, cl = k - tap * cke;
-            const int ky = tap / a.KW, kx = tap - ky * a.KW;
-            v = (cl * a.cplane + (ky * a.pitch + kx) * a.dil) * 4;
-        }
-        koff_base[idx] = v;
-    }
     const PlaneGeom pg{NI, a.inRows, a.pitch, a.colOff, a.cplane, a.invImg, a.invPitch, a.deal, 4};
     if (XTAB) {
         const int ixa = ix0 - a.colOff;
@@ -252,7 +316,7 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
     // issue the DMA of the chunk starting at channel c0 into stage `b`
     auto issue = [&](int c0, int b) {
         const int cke = min(a.CK, Cin - c0);
-        const int kchunk = (cke * KHW + 3) & ~3;
+        const int kchunk = (cke * KHW + kRowUnit - 1) & ~(kRowUnit - 1);
         float *in_lds = stage_base + b * stageFloats;
         float *w_lds = in_lds + a.CK * a.cplane;
         const float *wsrc = wslab + (long)(c0 / a.CK) * a.R4 * a.ldw;
@@ -284,8 +348,26 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
         }
     };
 
+    SPRK_DIAG_STAMP(1);
     __syncthreads();   // tables visible
+    SPRK_DIAG_STAMP(2);
     issue(0, 0);
+    SPRK_DIAG_STAMP(3);
+    // k-row byte offsets (tap-major inside a chunk) for a full chunk and for the last, possibly shorter one; built
+    // under the first chunk's DMA (the chunk loop's first barrier publishes them)
+    const int ckeLast = Cin - ((Cin - 1) / a.CK) * a.CK;
+    for (int idx = tid; idx < 2 * a.R4; idx += kBlock) {
+        const int which = idx >= a.R4, k = idx - which * a.R4;
+        const int cke = which ? ckeLast : a.CK;
+        int v = 0;
+        if (k < cke * KHW) {
+            const int tap = k / cke, cl = k - tap * cke;
+            const int ky = tap / a.KW, kx = tap - ky * a.KW;
+            v = (cl * a.cplane + (ky * a.pitch + kx) * a.dil) * 4;
+        }
+        koff_base[idx] = v;
+    }
+
     const int baddr0 = lds_addr(stage_base + a.CK * a.cplane + lq * a.ldw + l15);
     const int kaddr0 = lds_addr(koff_base + lq);
     const int abyte0 = lds_addr(stage_base);
@@ -295,15 +377,25 @@ __global__ __launch_bounds__(kBlock, 2) void conv_mfma_kernel(const ConvArgs a) 
         // every wave's DMA of this chunk has landed (vmcnt(0)) and every wave is done reading the
         // other stage (previous chunk) once all have passed the barrier
         __syncthreads();
+        if (c0 == 0) SPRK_DIAG_STAMP(4);
+        if (ci < 8) SPRK_DIAG_STAMP(8 + 3 * ci);
         if (c0 + a.CK < Cin) issue(c0 + a.CK, (ci + 1) & 1);
+        if (c0 == 0) SPRK_DIAG_STAMP(5);
+        if (ci < 8) SPRK_DIAG_STAMP(9 + 3 * ci);
         const int cke = min(a.CK, Cin - c0);
-        const int nkq = (cke * KHW + 3) >> 2;
+        const int nkq = ((cke * KHW + kRowUnit - 1) & ~(kRowUnit - 1)) >> 2;
         const int soff = (ci & 1) * stageFloats * 4;
         int ab[RB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) ab[r] = abyte0 + soff + abase[r];
-        chunk_mma<MT, NT, RB>(acc, ab, kaddr0 + (cke == a.CK ? 0 : a.R4 * 4), baddr0 + soff, bstep, nkq);
+        if constexpr (MT == 1 && NT <= 3)
+            chunk_mma_small<NT>(acc, ab[0], kaddr0 + (cke == a.CK ? 0 : a.R4 * 4), baddr0 + soff, bstep, nkq);
+        else
+            chunk_mma<MT, NT, RB>(acc, ab, kaddr0 + (cke == a.CK ? 0 : a.R4 * 4), baddr0 + soff, bstep, nkq);
+        if (c0 == 0) SPRK_DIAG_STAMP(6);
+        if (ci < 8) SPRK_DIAG_STAMP(10 + 3 * ci);
     }
+    SPRK_DIAG_STAMP(7);
 
 #include "conv_epilogue.inc"
 }
@@ -1021,17 +1113,35 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
         if (!p->xtab) p->nG1 = p->nG2 = 0;
     }
     // channels per K-chunk: two stages (double buffer) should leave room for 3 workgroups per CU
+    const int rowUnit = (MT == 1 && NT <= 3) ? 16 : 4;   // chunk_mma_small walks a chunk in groups of 4 k-steps
     auto lds = [&](int ck) {
-        const int r4 = sprk::roundup(ck * KHW, 4);
-        return (size_t)(2 * r4 + (p->nG1 + p->nG2) * 64 + 2 * (ck * p->cplane + r4 * p->ldw)) * 4;
+        const int r4 = sprk::roundup(ck * KHW, rowUnit);
+        const int stages = ck >= Ck ? 1 : 2;   // the whole of K in one chunk: nothing to double-buffer
+        return (size_t)(2 * r4 + (p->nG1 + p->nG2) * 64 + stages * (ck * p->cplane + r4 * p->ldw)) * 4;
     };
     int CK = std::max(1, std::min(Ck, KHW == 1 ? 16 : std::max(1, 36 / KHW)));
     while (CK > 1 && lds(CK) > 52 * 1024) CK >>= 1;
     // small tiles: longer K-chunks (fewer barriers) while the stages stay small
     while (CK * 2 <= Ck && CK * 2 * KHW <= 288 && lds(CK * 2) <= (size_t)(MT == 1 ? 64 : 24) * 1024) CK *= 2;
+    if (MT == 1 && blocks <= 2 * sprk::num_cus()) {
+        // planes of a few pixels on a grid the CUs hold at once: these launches are latency-bound (a workgroup's serial
+        // preamble -> DMA -> MFMA -> store chain, not the machine's throughput), and every chunk adds a DMA issue, a
+        // landing wait and a barrier to that chain: as few chunks as the LDS allows — all of K in one stage when it
+        // fits.  One workgroup per CU is all a grid of <= 256 workgroups needs, two up to 512; larger grids keep the
+        // smaller stages (more resident workgroups hide more latency than fewer chunks save: measured).
+        const size_t room = blocks <= sprk::num_cus() ? 156 * 1024 : 78 * 1024;
+        for (int nCh = 1; nCh <= Ck; ++nCh) {
+            const int ck = sprk::cdiv(Ck, nCh);
+            if (ck <= CK) break;
+            if (lds(ck) <= room) {
+                CK = ck;
+                break;
+            }
+        }
+    }
     if (lds(CK) > kLdsLimit) return false;
     p->CK = CK;
-    p->R4 = sprk::roundup(CK * KHW, 4);
+    p->R4 = sprk::roundup(CK * KHW, rowUnit);
     p->rows = sprk::cdiv(Ck, CK) * p->R4;
     p->ldsBytes = lds(CK);
     p->wsBytes = ((size_t)kZeroFloats + (size_t)p->nblkN * p->rows * p->ldw) * sizeof(float);
@@ -1337,6 +1447,13 @@ constexpr int kClassWino = 3;   // profiling class of the 96-channel Winograd ke
 // C ABI
 // ==========================================================================================
 extern "C" {
+
+#ifdef SPRK_DIAG
+// diagnostic builds only: the phase time stamps workgroup 0 of the last conv_mfma_kernel launch left (10 ns units)
+int sprk_diag_conv_clock(long long *out8) {
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(sprk_diag_conv_clk), 40 * sizeof(long long)) == hipSuccess ? SPRK_OK : SPRK_ELAUNCH;
+}
+#endif
 
 // Which calls of a layer exist for 16-bit ACTIVATION tensors (SPRK_DT_X16 / SPRK_DT_Y16)?  Bit 0: forward, bit 1:
 // backward-data, bit 2: backward-weight.  g->dtype carries the operand type; the storage bits are ignored (every
