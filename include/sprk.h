@@ -108,7 +108,7 @@ typedef struct sprk_conv_epilogue {
  * entry points exist).  A binding must refuse a library whose sprk_version() differs from the header it was
  * written against, and may compare sprk_struct_bytes(0 | 1 | 2) with its own sizeof(sprk_conv_geom |
  * sprk_conv_epilogue | sprk_reduce_item). */
-#define SPRK_ABI_VERSION 400
+#define SPRK_ABI_VERSION 410
 const char *sprk_last_error(void);
 int sprk_version(void);
 size_t sprk_struct_bytes(int which);
@@ -293,6 +293,32 @@ int sprk_reparam_bwd(const float *gz, const float *out_stats, const float *eps, 
 /* _sigmoid: clamp(sigmoid(x), 1e-4, 1-1e-4)  (denoiser_v2.py:32-34) */
 int sprk_sigmoid_clamp_fwd(const float *x, float *p, long n, void *stream);
 int sprk_sigmoid_clamp_bwd(const float *gp, const float *x, float *gx, long n, void *stream);
+/* Small fused pieces of the training step's tail (ABI 410).  Each replaces a chain of framework launches by one: a
+ * kernel of a replayed step costs ~5 us whatever it does, and these chains were a quarter of the step's launches.
+ *
+ * ResidA's residual (models/feature_extractor.py:384-416: x = x[:, :, edge:-edge, edge:-edge], optionally
+ * x[:, :, ::s, ::s]; y = y + x):   out[nc][i][j] = y[nc][i][j] + x[nc][off + s i][off + s j]   (y == NULL: the crop
+ * alone, for the 1x1 projection); NC = N * C planes, y / out [NC][Ho][Wo], x [NC][Hx][Wx].  crop_embed_bwd is the
+ * gradient with respect to x: g scattered to those positions, zero elsewhere (the gradient with respect to y is g). */
+int sprk_crop_add_fwd(const float *y, const float *x, float *out, long NC, int Ho, int Wo, int Hx, int Wx, int off, int stride,
+                      void *stream);
+int sprk_crop_embed_bwd(const float *g, float *gx, long NC, int Ho, int Wo, int Hx, int Wx, int off, int stride, void *stream);
+/* Noise level of an image from the estimator's map (denoiser_v2.py:392-402; NoiseValue.UNKNOWN_VARIABLE):
+ *   z[b] = mean(est[b]) - 4;  noise_std[b] = softplus(z[b]) + 1e-3   (softplus with torch's threshold 20)
+ * est [B][HW]; z is kept for the backward pass:  g_est[b][i] = g[b] * sigmoid(z[b]) / HW.  One workgroup per image
+ * (meant for patches; the whole-micrograph path keeps the framework's reduction). */
+int sprk_noise_std_fwd(const float *est, float *noise_std, float *z, int B, int HW, void *stream);
+int sprk_noise_std_bwd(const float *g, const float *z, float *g_est, int B, int HW, void *stream);
+/* The training loss of the joint pipeline (denoiser_v2.py:516-519):
+ *   consis[0] = mean((p - flip(pf))^2);   final[b] = alpha * loss_out[b] + (1 - alpha) * pred[0] + w_consis * consis[0]
+ * p, pf: [B][1][H][W] scores of the batch and of the flipped batch, pf NOT yet flipped back (axis 0: along W, 1: along
+ * H); loss_out [B] per-image denoising loss; pred [1] the PU loss.  joint_loss_bwd: g_final [B] ->
+ *   g_loss_out[b] = alpha g_final[b];  g_pred[0] = (1 - alpha) S;  gp = w_consis S 2 (p - flip(pf)) / n;  gpf = -flip(gp)
+ * with S = sum_b g_final[b], n = B H W.  One workgroup, sums in a fixed order. */
+int sprk_joint_loss_fwd(const float *loss_out, const float *pred, const float *p, const float *pf, float *final_loss,
+                        float *consis, int B, int H, int W, int axis, float alpha, float w_consis, void *stream);
+int sprk_joint_loss_bwd(const float *g_final, const float *p, const float *pf, float *g_loss_out, float *g_pred, float *gp,
+                        float *gpf, int B, int H, int W, int axis, float alpha, float w_consis, void *stream);
 /* PU detection loss and its gradient in one launch (utils/losses.py:303-349: BCE on the labelled patches + slack *
  * binomial generalised-expectation penalty on the unlabelled ones):
  *   y[i] >= 0: labelled with target y[i];  y[i] == -1: unlabelled;  N = number of unlabelled, n_lab of labelled

@@ -88,6 +88,12 @@ _SIGS = {
     "sprk_bn_train_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_i, c_vp, c_sz, c_vp]),
     "sprk_bn_eval_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, ctypes.c_float, c_i, c_vp]),
     "sprk_bn_train_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_vp, c_sz, c_vp]),
+    "sprk_crop_add_fwd": (c_i, [c_f, c_f, c_f, ctypes.c_long, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "sprk_crop_embed_bwd": (c_i, [c_f, c_f, ctypes.c_long, c_i, c_i, c_i, c_i, c_i, c_i, c_vp]),
+    "sprk_noise_std_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_vp]),
+    "sprk_noise_std_bwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_vp]),
+    "sprk_joint_loss_fwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_vp]),
+    "sprk_joint_loss_bwd": (c_i, [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, ctypes.c_float, ctypes.c_float, c_vp]),
     "sprk_reparam_fwd": (c_i, [c_f, c_f, c_f, c_i, c_i, c_vp]),
     "sprk_reparam_bwd": (c_i, [c_f, c_f, c_f, c_f, c_i, c_i, c_vp]),
     "sprk_adam_multi": (c_i, [c_vp, c_vp, c_i, c_i, c_f, c_f, c_f, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_vp]),
@@ -107,7 +113,7 @@ _SIGS = {
 }
 
 EXPORTS = tuple(_SIGS)
-ABI_VERSION = 400          # SPRK_ABI_VERSION of the include/sprk.h these signatures were written against
+ABI_VERSION = 410          # SPRK_ABI_VERSION of the include/sprk.h these signatures were written against
 _lib = None
 
 

@@ -545,7 +545,7 @@ template <bool POISSON>
 __global__ __launch_bounds__(kSsdnBlk) void ssdn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ o,
                                                             const float *__restrict__ ns, float *__restrict__ partial,
                                                             float *__restrict__ pme, float *__restrict__ mstd,
-                                                            float *__restrict__ nsmap, int HW) {
+                                                            float *__restrict__ nsmap, int HW, float *__restrict__ direct) {
     __shared__ float red[kSsdnBlk];
     const int b = blockIdx.y;
     const float e = ns[b];
@@ -568,7 +568,12 @@ __global__ __launch_bounds__(kSsdnBlk) void ssdn_fwd_kernel(const float *__restr
         if (POISSON && nsmap) nsmap[(long)b * HW + i] = s;
     }
     const float tot = block_sum(acc, red);
-    if (threadIdx.x == 0) partial[b * gridDim.x + blockIdx.x] = tot;
+    if (threadIdx.x == 0) {
+        if (direct)   // one workgroup per image (patches): the image's mean, no second launch
+            direct[b] = tot / (float)HW;
+        else
+            partial[b * gridDim.x + blockIdx.x] = tot;
+    }
 }
 
 __global__ void ssdn_finish_kernel(const float *__restrict__ partial, float *__restrict__ out, int B, int nblk,
@@ -583,7 +588,8 @@ __global__ void ssdn_finish_kernel(const float *__restrict__ partial, float *__r
 template <bool POISSON>
 __global__ __launch_bounds__(kSsdnBlk) void ssdn_bwd_kernel(const float *__restrict__ gl, const float *__restrict__ x,
                                                             const float *__restrict__ o, const float *__restrict__ ns,
-                                                            float *__restrict__ go, float *__restrict__ partial, int HW) {
+                                                            float *__restrict__ go, float *__restrict__ partial, int HW,
+                                                            float *__restrict__ direct) {
     __shared__ float red[kSsdnBlk];
     const int b = blockIdx.y;
     const float e = ns[b];
@@ -613,10 +619,122 @@ __global__ __launch_bounds__(kSsdnBlk) void ssdn_bwd_kernel(const float *__restr
         }
     }
     const float tot = block_sum(acc, red);
-    if (threadIdx.x == 0) partial[b * gridDim.x + blockIdx.x] = tot * g;
+    if (threadIdx.x == 0) {
+        if (direct)
+            direct[b] = tot * g;
+        else
+            partial[b * gridDim.x + blockIdx.x] = tot * g;
+    }
 }
 
-int ssdn_nblk(int HW) { return std::max(1, std::min(64, sprk::cdiv(HW, kSsdnBlk * 4))); }
+// ---- small fused pieces of the training step's tail: each replaces a chain of framework launches by one (a kernel of
+// a replayed step costs ~5 us whatever it does: profiles/r04_timeline_*) -------------------------------------------
+// ResidA (models/feature_extractor.py:384-416): out = y + x[:, :, off + s i, off + s j] (y == nullptr: the crop alone)
+__global__ void crop_add_fwd_kernel(const float *__restrict__ y, const float *__restrict__ x, float *__restrict__ out,
+                                    int Ho, int Wo, int Hx, int Wx, int off, int stride, long total) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % Wo);
+        const long t = idx / Wo;
+        const int i = (int)(t % Ho);
+        const long nc = t / Ho;
+        const float v = x[(nc * Hx + off + i * stride) * Wx + off + j * stride];
+        out[idx] = y ? y[idx] + v : v;
+    }
+}
+
+// its gradient with respect to x: g scattered into the cropped (strided) positions, zero elsewhere
+__global__ void crop_embed_bwd_kernel(const float *__restrict__ g, float *__restrict__ gx, int Ho, int Wo, int Hx, int Wx,
+                                      int off, int stride, long total) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int jx = (int)(idx % Wx);
+        const long t = idx / Wx;
+        const int ix = (int)(t % Hx);
+        const long nc = t / Hx;
+        const int a = ix - off, b = jx - off;
+        float v = 0.f;
+        if (a >= 0 && b >= 0 && a % stride == 0 && b % stride == 0) {
+            const int i = a / stride, j = b / stride;
+            if (i < Ho && j < Wo) v = g[(nc * Ho + i) * Wo + j];
+        }
+        gx[idx] = v;
+    }
+}
+
+// noise level of an image from the estimator's map (denoiser_v2.py:392-402):  z = mean(est) - 4,
+// out = softplus(z) + 1e-3 (softplus with torch's threshold 20).  One workgroup per image.
+__global__ __launch_bounds__(kSsdnBlk) void noise_std_fwd_kernel(const float *__restrict__ est, float *__restrict__ out,
+                                                                 float *__restrict__ z_out, int HW) {
+    __shared__ float red[kSsdnBlk];
+    const int b = blockIdx.x;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < HW; i += kSsdnBlk) acc += est[(long)b * HW + i];
+    const float z = block_sum(acc, red) / (float)HW - 4.0f;
+    if (threadIdx.x == 0) {
+        out[b] = (z > 20.f ? z : log1pf(expf(z))) + 1e-3f;
+        z_out[b] = z;
+    }
+}
+
+__global__ void noise_std_bwd_kernel(const float *__restrict__ g, const float *__restrict__ z, float *__restrict__ gest,
+                                     int HW, long total) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / HW);
+        const float zz = z[b];
+        const float sg = zz > 20.f ? 1.f : 1.f / (1.f + expf(-zz));
+        gest[idx] = g[b] * sg / (float)HW;
+    }
+}
+
+// the training loss of the joint pipeline (denoiser_v2.py:516-519):
+//   consis = mean((p - flip(pf))^2);   final[b] = alpha * loss_out[b] + (1 - alpha) * pred + wc * consis
+// p, pf: [B,1,H,W] scores of the batch and of the flipped batch (pf NOT yet flipped back: axis 0 = along W, 1 = along H).
+// One workgroup, sums in a fixed order.
+__device__ __forceinline__ int flip_index(int i, int H, int W, int axis) {
+    const int w = i % W, h = (i / W) % H, b = i / (W * H);
+    return (b * H + (axis ? H - 1 - h : h)) * W + (axis ? w : W - 1 - w);
+}
+
+__global__ __launch_bounds__(kSsdnBlk) void joint_loss_fwd_kernel(const float *__restrict__ loss_out,
+                                                                  const float *__restrict__ pred,
+                                                                  const float *__restrict__ p, const float *__restrict__ pf,
+                                                                  float *__restrict__ final_loss, float *__restrict__ consis,
+                                                                  int B, int n, int H, int W, int axis, float alpha, float wc) {
+    __shared__ float red[kSsdnBlk];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += kSsdnBlk) {
+        const float d = p[i] - pf[flip_index(i, H, W, axis)];
+        acc += d * d;
+    }
+    const float mse = block_sum(acc, red) / (float)n;
+    if (threadIdx.x == 0) consis[0] = mse;
+    const float rest = (1.f - alpha) * pred[0] + wc * mse;
+    for (int b = threadIdx.x; b < B; b += kSsdnBlk) final_loss[b] = alpha * loss_out[b] + rest;
+}
+
+__global__ __launch_bounds__(kSsdnBlk) void joint_loss_bwd_kernel(const float *__restrict__ go, const float *__restrict__ p,
+                                                                  const float *__restrict__ pf, float *__restrict__ g_loss_out,
+                                                                  float *__restrict__ g_pred, float *__restrict__ gp,
+                                                                  float *__restrict__ gpf, int B, int n, int H, int W,
+                                                                  int axis, float alpha, float wc) {
+    __shared__ float red[kSsdnBlk];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += kSsdnBlk) {
+        acc += go[b];
+        g_loss_out[b] = alpha * go[b];
+    }
+    const float S = block_sum(acc, red);
+    if (threadIdx.x == 0) g_pred[0] = (1.f - alpha) * S;
+    const float k = wc * S * 2.f / (float)n;
+    for (int i = threadIdx.x; i < n; i += kSsdnBlk) {
+        const int fi = flip_index(i, H, W, axis);
+        const float v = k * (p[i] - pf[fi]);
+        gp[i] = v;
+        gpf[fi] = -v;
+    }
+}
+
+// patches (<= 128x128): one workgroup per image writes the image's sum itself; larger images: partial sums + a finishing launch
+int ssdn_nblk(int HW) { return HW <= 16384 ? 1 : std::min(64, sprk::cdiv(HW, kSsdnBlk * 4)); }
 
 
 // ---- Adam over many parameter tensors in one launch --------------------------------------------------------------
@@ -813,6 +931,60 @@ int sprk_pu_loss(const float *p, const float *y, const float *log_binom, int B, 
     return sprk::check_launch("pu_loss");
 }
 
+int sprk_crop_add_fwd(const float *y, const float *x, float *out, long NC, int Ho, int Wo, int Hx, int Wx, int off, int stride,
+                      void *stream) {
+    SPRK_REQUIRE(x && out && NC > 0 && Ho > 0 && Wo > 0 && off >= 0 && stride > 0, "crop_add_fwd: bad arguments");
+    SPRK_REQUIRE(off + (Ho - 1) * stride < Hx && off + (Wo - 1) * stride < Wx, "crop_add_fwd: the crop leaves the source plane");
+    const long total = NC * Ho * Wo;
+    hipLaunchKernelGGL(crop_add_fwd_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y, x, out, Ho, Wo,
+                       Hx, Wx, off, stride, total);
+    return sprk::check_launch("crop_add_fwd");
+}
+
+int sprk_crop_embed_bwd(const float *g, float *gx, long NC, int Ho, int Wo, int Hx, int Wx, int off, int stride, void *stream) {
+    SPRK_REQUIRE(g && gx && NC > 0 && Ho > 0 && Wo > 0 && off >= 0 && stride > 0, "crop_embed_bwd: bad arguments");
+    SPRK_REQUIRE(off + (Ho - 1) * stride < Hx && off + (Wo - 1) * stride < Wx, "crop_embed_bwd: the crop leaves the source plane");
+    const long total = NC * Hx * Wx;
+    hipLaunchKernelGGL(crop_embed_bwd_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, g, gx, Ho, Wo,
+                       Hx, Wx, off, stride, total);
+    return sprk::check_launch("crop_embed_bwd");
+}
+
+int sprk_noise_std_fwd(const float *est, float *noise_std, float *z, int B, int HW, void *stream) {
+    SPRK_REQUIRE(est && noise_std && z && B > 0 && HW > 0, "noise_std_fwd: bad arguments");
+    hipLaunchKernelGGL(noise_std_fwd_kernel, dim3(B), dim3(kSsdnBlk), 0, (hipStream_t)stream, est, noise_std, z, HW);
+    return sprk::check_launch("noise_std_fwd");
+}
+
+int sprk_noise_std_bwd(const float *g, const float *z, float *g_est, int B, int HW, void *stream) {
+    SPRK_REQUIRE(g && z && g_est && B > 0 && HW > 0, "noise_std_bwd: bad arguments");
+    const long total = (long)B * HW;
+    hipLaunchKernelGGL(noise_std_bwd_kernel, dim3(sprk::ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, g, z, g_est, HW,
+                       total);
+    return sprk::check_launch("noise_std_bwd");
+}
+
+int sprk_joint_loss_fwd(const float *loss_out, const float *pred, const float *p, const float *pf, float *final_loss,
+                        float *consis, int B, int H, int W, int axis, float alpha, float w_consis, void *stream) {
+    SPRK_REQUIRE(loss_out && pred && p && pf && final_loss && consis && B > 0 && H > 0 && W > 0, "joint_loss_fwd: bad arguments");
+    SPRK_REQUIRE(axis == 0 || axis == 1, "joint_loss_fwd: axis is 0 (flip along W) or 1 (along H)");
+    SPRK_REQUIRE((long)B * H * W < (1L << 24), "joint_loss_fwd: score maps too large for the one-workgroup form");
+    hipLaunchKernelGGL(joint_loss_fwd_kernel, dim3(1), dim3(kSsdnBlk), 0, (hipStream_t)stream, loss_out, pred, p, pf, final_loss,
+                       consis, B, B * H * W, H, W, axis, alpha, w_consis);
+    return sprk::check_launch("joint_loss_fwd");
+}
+
+int sprk_joint_loss_bwd(const float *g_final, const float *p, const float *pf, float *g_loss_out, float *g_pred, float *gp,
+                        float *gpf, int B, int H, int W, int axis, float alpha, float w_consis, void *stream) {
+    SPRK_REQUIRE(g_final && p && pf && g_loss_out && g_pred && gp && gpf && B > 0 && H > 0 && W > 0,
+                 "joint_loss_bwd: bad arguments");
+    SPRK_REQUIRE(axis == 0 || axis == 1, "joint_loss_bwd: axis is 0 (flip along W) or 1 (along H)");
+    SPRK_REQUIRE((long)B * H * W < (1L << 24), "joint_loss_bwd: score maps too large for the one-workgroup form");
+    hipLaunchKernelGGL(joint_loss_bwd_kernel, dim3(1), dim3(kSsdnBlk), 0, (hipStream_t)stream, g_final, p, pf, g_loss_out,
+                       g_pred, gp, gpf, B, B * H * W, H, W, axis, alpha, w_consis);
+    return sprk::check_launch("joint_loss_bwd");
+}
+
 size_t sprk_ssdn_ws_bytes(int B, int HW) { return (size_t)B * ssdn_nblk(HW) * sizeof(float); }
 
 int sprk_ssdn_fwd(const float *x, const float *out_stats, const float *noise_std, float *loss, float *pme,
@@ -828,11 +1000,12 @@ int sprk_ssdn_fwd(const float *x, const float *out_stats, const float *noise_std
     hipStream_t s = (hipStream_t)stream;
     if (style == SPRK_NOISE_POISSON)
         hipLaunchKernelGGL(ssdn_fwd_kernel<true>, dim3(nblk, B), dim3(kSsdnBlk), 0, s, x, out_stats, noise_std, (float *)ws,
-                           pme, model_std, noise_std_map, HW);
+                           pme, model_std, noise_std_map, HW, nblk == 1 ? loss : nullptr);
     else
         hipLaunchKernelGGL(ssdn_fwd_kernel<false>, dim3(nblk, B), dim3(kSsdnBlk), 0, s, x, out_stats, noise_std, (float *)ws,
-                           pme, model_std, noise_std_map, HW);
+                           pme, model_std, noise_std_map, HW, nblk == 1 ? loss : nullptr);
     if (int rc = sprk::check_launch("ssdn_fwd")) return rc;
+    if (nblk == 1) return SPRK_OK;
     hipLaunchKernelGGL(ssdn_finish_kernel, dim3(sprk::cdiv(B, 64)), dim3(64), 0, s, (const float *)ws, loss, B, nblk,
                        1.0f / (float)HW);
     return sprk::check_launch("ssdn_finish");
@@ -852,11 +1025,12 @@ int sprk_ssdn_bwd(const float *gloss, const float *x, const float *out_stats, co
     hipStream_t s = (hipStream_t)stream;
     if (style == SPRK_NOISE_POISSON)
         hipLaunchKernelGGL(ssdn_bwd_kernel<true>, dim3(nblk, B), dim3(kSsdnBlk), 0, s, gloss, x, out_stats, noise_std,
-                           g_out_stats, (float *)ws, HW);
+                           g_out_stats, (float *)ws, HW, nblk == 1 ? g_noise_std : nullptr);
     else
         hipLaunchKernelGGL(ssdn_bwd_kernel<false>, dim3(nblk, B), dim3(kSsdnBlk), 0, s, gloss, x, out_stats, noise_std,
-                           g_out_stats, (float *)ws, HW);
+                           g_out_stats, (float *)ws, HW, nblk == 1 ? g_noise_std : nullptr);
     if (int rc = sprk::check_launch("ssdn_bwd")) return rc;
+    if (nblk == 1) return SPRK_OK;
     hipLaunchKernelGGL(ssdn_finish_kernel, dim3(sprk::cdiv(B, 64)), dim3(64), 0, s, (const float *)ws, g_noise_std, B,
                        nblk, 1.0f);
     return sprk::check_launch("ssdn_finish");

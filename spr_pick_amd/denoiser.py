@@ -171,6 +171,8 @@ class Denoiser(nn.Module):
             est = self.l_params[Denoiser.ESTIMATED_SIGMA].expand(noisy_in.shape[0], 1, 1, 1)
         elif nv == NoiseValue.UNKNOWN_VARIABLE:
             est = self.models[Denoiser.SIGMA_ESTIMATOR](noisy_in)
+            if est.shape[1] == 1 and est[0].numel() <= ops.NOISE_STD_MAX_PIXELS and est.dtype == torch.float32:
+                return ops.noise_std_from_map(est)      # patches: mean, shift, softplus and offset in one launch
             est = torch.mean(est, dim=(2, 3), keepdim=True)
         else:
             raise NotImplementedError("NoiseValue.KNOWN is not reachable from the joint pipeline "
@@ -267,7 +269,7 @@ class Denoiser(nn.Module):
             axis = -1 if p <= 0.5 else -2
             (net_out, hm_p), (_, hm_p_f) = model.forward_pair(inp, inp.flip(axis), eps, eps_flip)
             hm_p = _sigmoid(hm_p)
-            hm_p_f = _sigmoid(hm_p_f.flip(axis))
+            hm_p_f = _sigmoid(hm_p_f)         # of the flipped batch, not flipped back: ops.joint_loss reads it mirrored
             pred_loss = self._pu(tau, hm_p, self._labels_on_device(target))
         elif tile:
             net_out, hm_p, noise_std = self._tiled_networks(inp, eps, int(tile), int(halo))
@@ -281,8 +283,8 @@ class Denoiser(nn.Module):
             noise_std = self._noise_std(inp)
         loss_out, pme_out, net_std_out, ns_map = ops.ssdn_nll_pme(inp, net_out, noise_std, style)
         if train:
-            consis_loss = torch.nn.functional.mse_loss(hm_p, hm_p_f)
-            final_loss = alpha * loss_out + (1 - alpha) * pred_loss + 0.1 * consis_loss
+            # consis = mse(hm_p, flip(hm_p_f)); final = alpha * loss_out + (1 - alpha) * pred_loss + 0.1 * consis
+            final_loss, consis_loss = ops.joint_loss(loss_out, pred_loss, hm_p, hm_p_f, axis, alpha, 0.1)
         else:
             final_loss, pred_loss, consis_loss = loss_out, 0, 0
         return {

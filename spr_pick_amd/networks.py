@@ -384,10 +384,12 @@ class BatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self.groups = 1   # > 1: the batch holds that many stacked passes (JointNetwork.forward_pair)
+        self.count_outside = False   # the caller advances num_batches_tracked of all its layers in one launch
 
     def forward(self, x, relu=False):
         if self.training:
-            self.num_batches_tracked += self.groups
+            if not self.count_outside:
+                self.num_batches_tracked += self.groups
             return ops.batch_norm_train(x, self.weight, self.bias, self.running_mean, self.running_var,
                                         self.momentum, self.eps, relu, groups=self.groups)
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
@@ -501,12 +503,20 @@ class ResidA(nn.Module):
         if self.bn:
             t = self.bn0(t, relu=True)
         y = ops.conv2d(t, self.conv1.weight, self.conv1.bias, stride=s, dil=d1)
-        skip = x[:, :, e:-e, e:-e]
-        if has_proj:
-            skip = ops.conv2d(skip.contiguous(), self.proj.weight, None, stride=s)
-        elif s > 1:
-            skip = skip[:, :, ::s, ::s]
-        y = y + skip
+        if x.dtype == torch.float32 and y.dtype == torch.float32:
+            # crop (and stride) + add in one launch, the crop's gradient in one (slicing costs autograd two fills and
+            # two copies per crop on the way back)
+            if has_proj:
+                y = y + ops.conv2d(ops.crop_add(None, x, e), self.proj.weight, None, stride=s)
+            else:
+                y = ops.crop_add(y, x, e, s)
+        else:
+            skip = x[:, :, e:-e, e:-e]
+            if has_proj:
+                skip = ops.conv2d(skip.contiguous(), self.proj.weight, None, stride=s)
+            elif s > 1:
+                skip = skip[:, :, ::s, ::s]
+            y = y + skip
         if self.bn:
             return self.bn1(y, relu=True)
         return torch.relu(y)
@@ -651,13 +661,17 @@ class JointNetwork(nn.Module):
         if not self.training:
             return (out1, self.detector(self.reparameterize(out1, eps))), \
                    (out2, self.detector(self.reparameterize(out2, eps2)))
-        z = torch.cat((self.reparameterize(out1, eps), self.reparameterize(out2, eps2)), dim=0)
+        if eps is None or eps2 is None:
+            z = torch.cat((self.reparameterize(out1, eps), self.reparameterize(out2, eps2)), dim=0)
+        else:
+            z = self.reparameterize(both, torch.cat((eps, eps2), dim=0))     # the same per-pixel arithmetic, one launch
         bns = [m for m in self.detector.modules() if isinstance(m, BatchNorm2d)]
         for m in bns:
-            m.groups = 2
+            m.groups, m.count_outside = 2, True
         try:
             det = self.detector(z)
+            torch._foreach_add_([m.num_batches_tracked for m in bns], 2)   # one launch instead of one per layer
         finally:
             for m in bns:
-                m.groups = 1
+                m.groups, m.count_outside = 1, False
         return (out1, det[:B]), (out2, det[B:])

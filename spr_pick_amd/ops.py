@@ -571,6 +571,93 @@ def pu_loss(p, y, log_binom, slack=4.0):
     return _PuLossFn.apply(p, y, log_binom, slack)
 
 
+# ---- fused pieces of the training step's tail (include/sprk.h, ABI 410) --------------------------------------------
+class _CropAddFn(torch.autograd.Function):
+    """out = y + x[:, :, off::stride, off::stride][:, :, :Ho, :Wo]   (y None: the crop alone)"""
+
+    @staticmethod
+    def forward(ctx, y, x, off, stride, out_h, out_w):
+        x = x.contiguous()
+        y = None if y is None else y.contiguous()
+        _need_gpu(x, y)
+        if x.dtype != _F32 or (y is not None and (y.dtype != _F32 or tuple(y.shape) != (x.shape[0], x.shape[1], out_h, out_w))):
+            raise ValueError("crop_add: fp32 tensors, y of the cropped shape")
+        ctx.geo = (off, stride, x.shape[2], x.shape[3], y is not None)
+        return _S.crop_add_fwd(y, x, off, stride, out_h, out_w)
+
+    @staticmethod
+    def backward(ctx, g):
+        off, stride, hx, wx, has_y = ctx.geo
+        g = g.contiguous()
+        gx = _S.crop_embed_bwd(g, off, stride, hx, wx) if ctx.needs_input_grad[1] else None
+        return (g if has_y else None), gx, None, None, None, None
+
+
+def crop_add(y, x, off, stride=1):
+    """ResidA's residual (models/feature_extractor.py:403-411): y + x[:, :, off:-off, off:-off][:, :, ::stride, ::stride]
+    in one launch, its gradient for x (zero-embedded) in one launch.  y None: the cropped copy alone."""
+    hc, wc = x.shape[2] - 2 * off, x.shape[3] - 2 * off
+    out_h, out_w = (hc + stride - 1) // stride, (wc + stride - 1) // stride
+    return _CropAddFn.apply(y, x, int(off), int(stride), out_h, out_w)
+
+
+class _NoiseStdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, est):
+        est = est.contiguous()
+        _need_gpu(est)
+        out, z = _S.noise_std_fwd(est)
+        ctx.save_for_backward(z)
+        ctx.shape = tuple(est.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        _, c, h, w = ctx.shape
+        return _S.noise_std_bwd(g.reshape(-1).contiguous(), z, c, h, w)
+
+
+NOISE_STD_MAX_PIXELS = 1 << 16
+
+
+def noise_std_from_map(est):
+    """softplus(mean(est, (1,2,3)) - 4) + 1e-3 per image -> [B,1,1,1] (denoiser_v2.py:392-402), one launch each way.
+    One workgroup per image: for patches; callers keep torch's reduction for whole micrographs (NOISE_STD_MAX_PIXELS)."""
+    return _NoiseStdFn.apply(est)
+
+
+class _JointLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loss_out, pred, p, pf, axis, alpha, wc):
+        pshape = tuple(pred.shape)
+        loss_out, pred = loss_out.contiguous(), pred.reshape(1).contiguous()
+        p, pf = p.contiguous(), pf.contiguous()
+        _need_gpu(loss_out, pred, p, pf)
+        if p.dim() != 4 or p.shape[1] != 1 or p.shape != pf.shape or loss_out.numel() != p.shape[0]:
+            raise ValueError("joint_loss: scores [B,1,H,W] twice and one denoising loss per image")
+        final, consis = _S.joint_loss_fwd(loss_out, pred, p, pf, axis, float(alpha), float(wc))
+        ctx.save_for_backward(p, pf)
+        ctx.cfg = (axis, float(alpha), float(wc), tuple(loss_out.shape), pshape)
+        ctx.mark_non_differentiable(consis)
+        return final.reshape(loss_out.shape), consis.reshape(())
+
+    @staticmethod
+    def backward(ctx, g, _gc):
+        p, pf = ctx.saved_tensors
+        axis, alpha, wc, lshape, pshape = ctx.cfg
+        gl, gpred, gp, gpf = _S.joint_loss_bwd(g.reshape(-1).contiguous(), p, pf, axis, alpha, wc)
+        return gl.reshape(lshape), gpred.reshape(pshape), gp, gpf, None, None, None
+
+
+def joint_loss(loss_out, pred_loss, p, pf_unflipped, axis, alpha, w_consis=0.1):
+    """(final [B,1], consis []) of the joint training step (denoiser_v2.py:516-519):
+    consis = mse(p, flip(pf, axis)), final = alpha * loss_out + (1 - alpha) * pred_loss + w_consis * consis.
+    axis: -1 / 3 (W) or -2 / 2 (H).  consis is returned for the logs only (its gradient flows through final)."""
+    ax = {-1: 0, 3: 0, -2: 1, 2: 1}[int(axis)]
+    return _JointLossFn.apply(loss_out, pred_loss, p, pf_unflipped, ax, alpha, w_consis)
+
+
 NOISE_GAUSSIAN, NOISE_POISSON = 0, 1      # SPRK_NOISE_* (include/sprk.h)
 
 

@@ -327,6 +327,62 @@ _simple("sigmoid_clamp_bwd", "(Tensor gp, Tensor x) -> Tensor", "sprk_sigmoid_cl
         lambda a, y: (_p(a[0]), _p(a[1]), _p(y), a[1].numel()))
 
 
+# ---- fused pieces of the training step's tail (include/sprk.h, ABI 410) ---------------------------------------------------
+def _crop_shape(x, off, stride, out_h, out_w):
+    return (x.shape[0], x.shape[1], out_h, out_w)
+
+
+def _crop_add(y, x, off, stride, out_h, out_w):
+    out = _f32(x, _crop_shape(x, off, stride, out_h, out_w))
+    check(_lib.lib().sprk_crop_add_fwd(_p(y), _p(x), _p(out), x.shape[0] * x.shape[1], out_h, out_w, x.shape[2], x.shape[3],
+                                       off, stride, _stream(x)), "sprk_crop_add_fwd")
+    return out
+
+
+_register("crop_add_fwd", "(Tensor? y, Tensor x, int off, int stride, int out_h, int out_w) -> Tensor", _crop_add,
+          lambda y, x, off, stride, out_h, out_w: x.new_empty(_crop_shape(x, off, stride, out_h, out_w)))
+_simple("crop_embed_bwd", "(Tensor g, int off, int stride, int hx, int wx) -> Tensor", "sprk_crop_embed_bwd",
+        lambda g, off, stride, hx, wx: (g.shape[0], g.shape[1], hx, wx),
+        lambda a, y: (_p(a[0]), _p(y), a[0].shape[0] * a[0].shape[1], a[0].shape[2], a[0].shape[3], a[3], a[4], a[1], a[2]))
+
+
+def _noise_std_fwd(est):
+    B, HW = est.shape[0], est[0].numel()
+    out, z = _f32(est, (B, 1, 1, 1)), _f32(est, (B,))
+    check(_lib.lib().sprk_noise_std_fwd(_p(est), _p(out), _p(z), B, HW, _stream(est)), "sprk_noise_std_fwd")
+    return out, z
+
+
+_register("noise_std_fwd", "(Tensor est) -> (Tensor, Tensor)", _noise_std_fwd,
+          lambda est: (est.new_empty((est.shape[0], 1, 1, 1)), est.new_empty((est.shape[0],))))
+_simple("noise_std_bwd", "(Tensor g, Tensor z, int c, int h, int w) -> Tensor", "sprk_noise_std_bwd",
+        lambda g, z, c, h, w: (z.shape[0], c, h, w),
+        lambda a, y: (_p(a[0]), _p(a[1]), _p(y), a[1].shape[0], a[2] * a[3] * a[4]))
+
+
+def _joint_loss_fwd(loss_out, pred, p, pf, axis, alpha, wc):
+    B, H, W = p.shape[0], p.shape[2], p.shape[3]
+    final, consis = _f32(p, (B, 1)), _f32(p, (1,))
+    check(_lib.lib().sprk_joint_loss_fwd(_p(loss_out), _p(pred), _p(p), _p(pf), _p(final), _p(consis), B, H, W, axis,
+                                         ctypes.c_float(alpha), ctypes.c_float(wc), _stream(p)), "sprk_joint_loss_fwd")
+    return final, consis
+
+
+def _joint_loss_bwd(g, p, pf, axis, alpha, wc):
+    B, H, W = p.shape[0], p.shape[2], p.shape[3]
+    gl, gpred, gp, gpf = _f32(p, (B, 1)), _f32(p, (1,)), _f32(p, tuple(p.shape)), _f32(p, tuple(p.shape))
+    check(_lib.lib().sprk_joint_loss_bwd(_p(g), _p(p), _p(pf), _p(gl), _p(gpred), _p(gp), _p(gpf), B, H, W, axis,
+                                         ctypes.c_float(alpha), ctypes.c_float(wc), _stream(p)), "sprk_joint_loss_bwd")
+    return gl, gpred, gp, gpf
+
+
+_register("joint_loss_fwd", "(Tensor loss_out, Tensor pred, Tensor p, Tensor pf, int axis, float alpha, float wc) -> (Tensor, Tensor)",
+          _joint_loss_fwd, lambda lo, pred, p, pf, axis, alpha, wc: (p.new_empty((p.shape[0], 1)), p.new_empty((1,))))
+_register("joint_loss_bwd", "(Tensor g, Tensor p, Tensor pf, int axis, float alpha, float wc) -> (Tensor, Tensor, Tensor, Tensor)",
+          _joint_loss_bwd, lambda g, p, pf, axis, alpha, wc: (p.new_empty((p.shape[0], 1)), p.new_empty((1,)),
+                                                             p.new_empty(p.shape), p.new_empty(p.shape)))
+
+
 def _pu_loss(p, y, log_binom, slack):
     """-> (loss [1], d loss / d p [B]) in one launch."""
     B = p.numel()

@@ -1157,3 +1157,69 @@ def test_fused_head_on_the_rotated_stack_is_bit_identical_to_unrot_plus_head(B, 
             assert torch.equal(got, ops.head1x1(f, c1, c2, c3))
         close(got, c3(c2(c1(f))), name="vs three launches")
     assert tuple(got.shape) == (B, N3, P, P)
+
+
+@pytest.mark.parametrize("off,stride,with_y", [(3, 1, True), (6, 2, True), (3, 1, False), (1, 2, False)])
+def test_crop_add_matches_slicing(off, stride, with_y):
+    """ResidA's residual (models/feature_extractor.py:403-411) as one launch each way: values and both gradients equal
+    autograd's slicing exactly (the op only moves and adds numbers)."""
+    from spr_pick_amd import ops
+    torch.manual_seed(off * 10 + stride)
+    x = torch.randn(3, 5, 23, 21, device="cuda", requires_grad=True)
+    xr = x.detach().clone().requires_grad_(True)
+    ref_crop = xr[:, :, off:-off, off:-off][:, :, ::stride, ::stride]
+    y = torch.randn_like(ref_crop).requires_grad_(True) if with_y else None
+    yr = y.detach().clone().requires_grad_(True) if with_y else None
+    out = ops.crop_add(y, x, off, stride)
+    ref = ref_crop + yr if with_y else ref_crop
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    g = torch.randn_like(out)
+    out.backward(g)
+    ref.backward(g)
+    assert torch.equal(x.grad, xr.grad)
+    if with_y:
+        assert torch.equal(y.grad, yr.grad)
+
+
+def test_noise_std_from_map_matches_torch():
+    """softplus(mean(est) - 4) + 1e-3 (denoiser_v2.py:392-402), incl. the threshold-20 branch and very negative means."""
+    from spr_pick_amd import ops
+    torch.manual_seed(5)
+    est = torch.randn(7, 1, 64, 64, device="cuda") * 0.3
+    est += torch.tensor([0.0, 2.0, 4.0, 8.0, 30.0, -20.0, 3.9], device="cuda").view(-1, 1, 1, 1)
+    a, b = est.clone().requires_grad_(True), est.clone().double().requires_grad_(True)
+    out = ops.noise_std_from_map(a)
+    ref = F.softplus(torch.mean(b, dim=(2, 3), keepdim=True) - 4.0) + 1e-3
+    assert out.shape == (7, 1, 1, 1)
+    assert torch.allclose(out.double(), ref, rtol=2e-6, atol=1e-9), float((out.double() - ref).abs().max())
+    g = torch.randn_like(out)
+    out.backward(g)
+    ref.backward(g.double())
+    assert torch.allclose(a.grad.double(), b.grad, rtol=2e-6, atol=1e-12), float((a.grad.double() - b.grad).abs().max())
+
+
+@pytest.mark.parametrize("axis", [-1, -2])
+@pytest.mark.parametrize("shape", [(32, 1, 1, 1), (5, 1, 3, 4)])
+def test_joint_loss_matches_torch(axis, shape):
+    """final = alpha * loss_out + (1 - alpha) * pred + 0.1 * mse(p, flip(pf)) (denoiser_v2.py:516-519) and its four
+    gradients against autograd on the reference's own formula, in fp64."""
+    from spr_pick_amd import ops
+    torch.manual_seed(11)
+    B, alpha = shape[0], 0.75
+    lo = torch.rand(B, 1, device="cuda") * 3
+    pred = torch.rand((), device="cuda") * 2
+    p, pf = torch.rand(shape, device="cuda"), torch.rand(shape, device="cuda")
+    t = [v.clone().requires_grad_(True) for v in (lo, pred, p, pf)]
+    r = [v.clone().double().requires_grad_(True) for v in (lo, pred, p, pf)]
+    final, consis = ops.joint_loss(t[0], t[1], t[2], t[3], axis, alpha, 0.1)
+    consis_ref = F.mse_loss(r[2], r[3].flip(axis))
+    final_ref = alpha * r[0] + (1 - alpha) * r[1] + 0.1 * consis_ref
+    assert final.shape == (B, 1) and consis.shape == ()
+    assert torch.allclose(consis.double(), consis_ref, rtol=1e-6, atol=1e-9)
+    assert torch.allclose(final.double(), final_ref, rtol=1e-6, atol=1e-7)
+    g = torch.rand(B, 1, device="cuda")
+    final.backward(g)
+    final_ref.backward(g.double())
+    for a, b, name in zip(t, r, ("loss_out", "pred", "p", "pf")):
+        assert a.grad.shape == a.shape, name
+        assert torch.allclose(a.grad.double(), b.grad, rtol=2e-6, atol=1e-9), (name, float((a.grad.double() - b.grad).abs().max()))
