@@ -22,6 +22,13 @@ gaps=collections.Counter()
 for (s0,e0,n0),(s1,e1,n1) in zip(a, a[1:]):
     g=s1-e0
     if g>20000: gaps[n1[:60]]+=g
+pairs=collections.Counter(); cnt=collections.Counter()
+for (s0,e0,n0),(s1,e1,n1) in zip(a, a[1:]):
+    g=s1-e0
+    if g>20000:
+        k=(n0.replace("void ","").replace("(anonymous namespace)::","")[:50], n1.replace("void ","").replace("(anonymous namespace)::","")[:50]); pairs[k]+=g; cnt[k]+=1
+print("idle gaps > 20 us by (kernel before -> kernel after): total ms, count, mean us")
+for k,v in pairs.most_common(10): print("  %8.2f %6d %7.1f   %s  ->  %s" % (v/1e6, cnt[k], v/1e3/cnt[k], k[0], k[1]))
 print("largest idle gaps BEFORE kernel (ms total):")
 for k,v in gaps.most_common(8): print("  %8.2f  %s" % (v/1e6, k))
 agg=collections.Counter()

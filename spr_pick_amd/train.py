@@ -225,7 +225,7 @@ class DenoiserTrainer:
                     train_history["aug_loss"] += outputs[PipelineOutput.AUG_LOSS].unsqueeze(0)
                 for key in (PipelineOutput.NOISE_STD_DEV, PipelineOutput.MODEL_STD_DEV):
                     if key in outputs:
-                        train_history[key.value] += outputs[key] * 255
+                        train_history[key.value].add(outputs[key], scale=255.0)
             self.state[StateValue.ITERATION] += image_count
 
         st = self._stepper

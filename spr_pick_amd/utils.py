@@ -77,14 +77,26 @@ class Metric:
         self.total = None
         self.n = 0
 
-    def add(self, value):
+    def add(self, value, scale=1.0):
+        """``scale``: a constant factor of the logged quantity (the loop logs standard deviations x 255), folded
+        into the accumulation instead of a launch of its own."""
         samples = value.shape[0] if self.batched else 1
         lead = 1 if self.batched else 0
-        if self.collapse and value.dim() > lead:
-            value = value.mean(dim=tuple(range(lead, value.dim())))
-        if self.batched:
-            value = value.sum(dim=0)
-        self.total = value if self.n == 0 or self.total is None else self.total + value
+        if self.collapse and self.batched:
+            # mean over the non-sample axes, then sum over the samples = sum of everything / elements per sample:
+            # one reduction (none for a one-element tensor) and one add per step instead of three launches
+            per = max(value.numel() // max(samples, 1), 1)
+            value = value.sum() if value.numel() > 1 else value.reshape(())
+            scale = scale / per
+        else:
+            if self.collapse and value.dim() > lead:
+                value = value.mean(dim=tuple(range(lead, value.dim())))
+            if self.batched:
+                value = value.sum(dim=0)
+        if self.n == 0 or self.total is None:
+            self.total = value * scale if scale != 1.0 else value
+        else:
+            self.total = self.total.add(value, alpha=scale)
         self.n += samples
 
     def __add__(self, value):     # ``metric += tensor`` in the training loop
