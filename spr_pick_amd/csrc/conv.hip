@@ -1313,13 +1313,22 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
         const int ioffN = sprk::roundup(sprk::roundup(ck * KHW, 16), 4);
         return (size_t)(ioffN + 64 + 16 + 2 * (p->nG1 + p->nG2) * 64 + 2 * (ck * p->cplane + NT * 16 * 64)) * 4;
     };
-    int CKW = 0, bestCost = 1 << 30;
+    // The cost of a split is the time of ONE workgroup (they all run at once: never more workgroups than CUs, see
+    // below): tiles per workgroup x (the busiest wave's k-tiles + a little for staging the G tile again).  With many
+    // tiles that is proportional to chunks x k-tiles, the total work; with few tiles (the U-Net levels <= 16x16: every
+    // workgroup has one tile whatever the split) it is the k-tiles alone, so small planes are cut into more, shorter
+    // chunks on more CUs (96->96 at 64x8x8: 2 chunks of 7 k-tiles per wave -> 4 of 4).
+    static const int kWgKnob = dbg_int("SPRK_WG_BLOCKS", 0);   // debug knob (sweeps); default: one workgroup per CU
+    const int kWgBlocks = kWgKnob > 0 ? kWgKnob : sprk::num_cus();
+    int CKW = 0;
+    long bestCost = 1L << 60;
     for (int nCh = 1; nCh <= Cin; ++nCh) {
         const int ck = sprk::cdiv(Cin, nCh);
         if (sprk::cdiv(Cin, ck) != nCh) continue;
         const int itw = sprk::cdiv(sprk::cdiv(ck * KHW, 16), 4);
         if (itw > kMaxIT || lds(ck) > 150 * 1024 || (p->xrow && ck > 192)) continue;
-        const int cost = nCh * (4 * itw + 1);
+        const int g = std::max(1, std::min(p->nTiles, kWgBlocks / (nCh * p->nblkN)));
+        const long cost = (long)sprk::cdiv(p->nTiles, g) * (4 * itw + 1);
         if (cost < bestCost) {
             bestCost = cost;
             CKW = ck;
@@ -1335,8 +1344,6 @@ bool plan_wgrad(const sprk_conv_geom *g, WgPlan *p) {
     // one workgroup per CU (the stages fill most of the LDS): never more workgroups than CUs, or the
     // surplus runs as a second, nearly empty round
     const int per = p->nChunks * p->nblkN;
-    static const int kWgKnob = dbg_int("SPRK_WG_BLOCKS", 0);   // debug knob (sweeps); default: one workgroup per CU
-    const int kWgBlocks = kWgKnob > 0 ? kWgKnob : sprk::num_cus();
     int groups = std::max(1, std::min(p->nTiles, kWgBlocks / per));
     p->tilesPerGroup = sprk::cdiv(p->nTiles, groups);
     p->groups = sprk::cdiv(p->nTiles, p->tilesPerGroup);

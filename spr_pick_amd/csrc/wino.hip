@@ -823,7 +823,10 @@ bool wino_eligible(const WinoGeom &g) {
     if (g.C1 < 1 || g.C2 < 0 || g.Cout < 33) return false;
     const int NT = nt_of(g.Cout), groups = cdiv(g.Cout, NT * 16);
     if ((double)g.Cout / (groups * NT * 16) < 0.7) return false;   // padded output channels are wasted MFMAs
-    if (!g.pin && (long)g.N * (g.H / TR) * (g.W / TC) * groups < 192) return false;   // too few workgroups for 256 CUs
+    // too few workgroups for 256 CUs: the direct kernel spreads the same layer over all of them, this one does 4/9 of
+    // the MFMA work on as many CUs as it has 256-pixel tiles — break-even near 256 x 4/9 = 114 (measured: 96->96 at
+    // 128x16x16, 128 tiles, 68 us direct)
+    if (!g.pin && (long)g.N * (g.H / TR) * (g.W / TC) * groups < 128) return false;
     if ((long)4 * g.H * g.W * 4 >= 0x7FFFFFFFL) return false;               // 4 planes inside one buffer range
     return true;
 }
