@@ -1097,7 +1097,8 @@ bool plan_fwd(int Nimg, int Ck, int Nn, int Ho, int Wo, int KH, int KW, int stri
         MT >>= 1;
         blocks = geometry(MT, NT);
     }
-    while (blocks < 512 && NT > 1) {
+    static const int kNtBlocks = dbg_int("SPRK_FWD_NTBLK", 512);   // debug knob (sweeps)
+    while (blocks < kNtBlocks && NT > 1) {
         NT = (NT == 6) ? 3 : (NT == 4) ? 2 : 1;
         blocks = geometry(MT, NT);
     }
