@@ -358,8 +358,8 @@ def main():
     ap.add_argument("--full-pipeline", choices=("on", "off"), default="on",
                     help="BASELINE configs[4] in small through the `joint` CLI (full_pipeline.py): train on a synthetic set on "
                          "disk, evaluate the final weights, recall / precision of the picks against the planted particles")
-    ap.add_argument("--full-pipeline-args", default="--micrographs 16 --iterations 96000 --batch 16 --dtypes f32,mixed16 "
-                                                    "--agreement f16 --print-interval 9600")
+    ap.add_argument("--full-pipeline-args", default="--micrographs 16 --iterations 160000 --batch 16 --dtypes f32,mixed16 "
+                                                    "--agreement f16 --print-interval 16000")
     ap.add_argument("--infer-size", type=int, default=1024, help="side of the small inference micrograph (0 = skip)")
     ap.add_argument("--infer-large", type=int, default=4096, help="side of the configs[2] micrograph (0 = skip)")
     args = ap.parse_args()

@@ -185,6 +185,9 @@ def main(argv=None, quiet=False):
     ap.add_argument("--micrographs", type=int, default=512)
     ap.add_argument("--train-micrographs", type=int, default=0, help="train on the first K micrographs (0 = all)")
     ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--format", default="mrc", choices=("mrc", "png"),
+                    help="micrograph files: float32 MRC (loaded min-max-scaled to [0, 1]) or 8-bit PNG of the standardised "
+                         "image (loaded as [-3, 3], background 0)")
     ap.add_argument("--iterations", type=int, default=80000)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--alpha", type=float, default=0.75)
@@ -202,15 +205,17 @@ def main(argv=None, quiet=False):
     work = args.work or tempfile.mkdtemp(prefix="sprk_full_")
     from spr_pick_amd import synthetic
     t0 = time.perf_counter()
-    ds = synthetic.write_dataset(os.path.join(work, "set"), args.micrographs, size=args.size)
+    ds = synthetic.write_dataset(os.path.join(work, "set"), args.micrographs, size=args.size, fmt=args.format)
     train_ds = ds
     if args.train_micrographs and args.train_micrographs < args.micrographs:
-        train_ds = synthetic.write_dataset(os.path.join(work, "set_train"), args.train_micrographs, size=args.size)
+        train_ds = synthetic.write_dataset(os.path.join(work, "set_train"), args.train_micrographs, size=args.size, fmt=args.format)
     out = {"workload": "BASELINE configs[4] on %s GPU(s): joint train start (%d iterations = images, batch %d, alpha %s, tau %s, "
                        "nms 18, bb 24) on %d synthetic %dx%d micrographs (%d labelled of %d planted particles), then joint "
                        "eval of the final weights on %d micrographs" % (
                            os.environ.get("WORLD_SIZE", "1"), args.iterations, args.batch, args.alpha, args.tau, train_ds["n"],
                            args.size, args.size, train_ds["labelled"], train_ds["planted"], ds["n"]),
+           "micrograph_files": ("float32 MRC, loaded min-max-scaled to [0, 1] (utils/loader.py:49-59)" if args.format == "mrc" else
+                                "8-bit PNG of the standardised image, loaded as [-3, 3] (utils/loader.py:72-82)"),
            "dataset_write_s": time.perf_counter() - t0, "runs": {}}
     picks_by, wts = {}, {}
     for dtype in args.dtypes.split(","):

@@ -5,8 +5,15 @@ final weights) through this package's CLI on a synthetic micrograph set ON DISK,
 Only 14 of the ~200 particles per micrograph are labelled (README.md:29: part of the particles of a 300x300 sub-region),
 the rest is learnt through the positive-unlabelled loss (utils/losses.py:303-349).
 
-Shortened run: 96 000 iterations (images) at batch 16 = 6 000 optimiser steps (~65 s) instead of 80 000 at batch 4 =
-20 000 steps; the full-size runs are recorded in profiles/r04_full_pipeline.json (full_pipeline.py)."""
+Shortened run: 160 000 iterations (images) at batch 16 = 10 000 optimiser steps (~100 s) instead of 80 000 at batch 4 =
+20 000 steps; the full-size runs are recorded in profiles/r04_full_pipeline_*.json (full_pipeline.py).
+
+Whether a trained model's picks survive the step from 64x64 patches to whole micrographs is fragile in the reference's
+algorithm (the blind-spot U-Net's output level moves with the context its 315 px receptive field sees, and
+a BatchNorm on a signal of variance 6e-4 sits behind it); runs are deterministic, so a configuration's outcome changes
+only when the arithmetic does — it did in round 4: the 6 000-step configuration pinned until then stopped writing picks
+in fp32 when the small-plane convolutions changed their summation order, 8 000 and 10 000 steps give AP 0.92 in fp32 and
+mixed16 (scratch/r4/fp_variants.sh).  The patch-level figures below are the robust statement."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -14,8 +21,8 @@ pytestmark = pytest.mark.gpu
 
 def test_trained_model_recovers_the_planted_particles(tmp_path):
     import full_pipeline
-    out = full_pipeline.main(["--micrographs", "16", "--iterations", "96000", "--batch", "16", "--dtypes", "f32",
-                              "--agreement", "f16", "--print-interval", "9600", "--work", str(tmp_path)])
+    out = full_pipeline.main(["--micrographs", "16", "--iterations", "160000", "--batch", "16", "--dtypes", "f32",
+                              "--agreement", "f16", "--print-interval", "16000", "--work", str(tmp_path)])
     run = out["runs"]["f32"]
     train, ev = run["train"], run["eval"]
     # the trainer's loop ran the graph-replayed step (no silent eager fallback) and learnt
@@ -30,8 +37,8 @@ def test_trained_model_recovers_the_planted_particles(tmp_path):
     m = ev["picks_vs_planted_centres"]
     assert m["micrographs"] == 16 and m["n_truth"] == 16 * 200
     print("picks vs planted centres:", m)
-    # measured on MI355X: AP 0.929; at the reference exporter's default threshold 0.13 (convert_to_star.py) precision 0.95,
-    # recall 0.91; best F1 0.94.  Floors leave room for other hardware summation orders, not for a model that has not learnt
+    # measured on MI355X: AP 0.925; at the reference exporter's default threshold 0.13 (convert_to_star.py) precision 0.99,
+    # recall 0.91.  Floors leave room for other hardware summation orders, not for a model that has not learnt
     assert m["average_precision"] >= 0.85, m
     assert m["best_f1"]["recall"] >= 0.85 and m["best_f1"]["precision"] >= 0.90, m["best_f1"]
     at = m["at"][0.13]
