@@ -6,6 +6,7 @@ import io
 import os
 
 import numpy as np
+import pytest
 import torch
 
 
@@ -103,3 +104,49 @@ def test_scores_roundtrip_and_dataset_on_disk(tmp_path):
     for cy, cx in labelled:
         assert hm[cy, cx] == 1.0
     assert (hm >= 0).sum() <= len(labelled) * 169
+
+
+def test_png_dataset_is_the_standardised_image_on_the_loaders_png_path(tmp_path):
+    """write_dataset(fmt="png"): 8-bit PNG levels of the standardised micrograph; the loader's PNG branch
+    (utils/loader.py:72-82: unquantize to [-3, 3]) hands the network a zero-centred image with the same particles as
+    the MRC variant of the same index."""
+    from spr_pick_amd import coordinates, micrograph_io, synthetic
+    ds = synthetic.write_dataset(str(tmp_path / "png"), 2, size=256, blobs=12, fmt="png")
+    assert ds["format"] == "png" and ds["planted"] == 24
+    rows = micrograph_io.read_image_table(ds["images"])
+    assert all(r[2].endswith(".png") for r in rows)
+    img = micrograph_io.load_image(rows[1][2])
+    assert img.dtype == np.float32 and img.shape == (256, 256)
+    assert abs(float(img.mean())) < 0.05 and 0.2 < float(img.std()) < 0.3 and -3.0 <= img.min() and img.max() <= 3.0
+    q, centres, labelled = synthetic.micrograph_standardised(1, size=256, blobs=12)
+    assert np.allclose(img, micrograph_io.unquantize(q))
+    _, centres_mrc, labelled_mrc = synthetic.micrograph(1, size=256, blobs=12)
+    assert np.array_equal(centres, centres_mrc) and np.array_equal(labelled, labelled_mrc)
+    cy, cx = centres[0]
+    assert img[cy, cx] < img.mean() - 0.2                      # a particle is a dark blob, 1.5 sigma deep
+    truth = coordinates.read_coordinates(ds["truth"])
+    assert len(truth) == 24
+    with pytest.raises(ValueError):
+        synthetic.write_dataset(str(tmp_path / "bad"), 1, size=256, fmt="tiff")
+
+
+def test_metric_accumulates_the_per_sample_mean_in_one_reduction():
+    """utils.Metric: mean over the non-sample axes, summed over the samples, divided by the sample count — the fused
+    form (one sum + one add per step, an optional constant factor folded in) equals the three-operator definition."""
+    import torch
+    from spr_pick_amd import utils
+    g = torch.Generator().manual_seed(3)
+    vals = [torch.rand(4, 1, 8, 8, generator=g) for _ in range(3)]
+    m = utils.Metric()
+    for v in vals:
+        m.add(v, scale=255.0)
+    want = sum((v * 255).mean(dim=(1, 2, 3)).sum(dim=0) for v in vals) / 12
+    assert m.n == 12 and torch.allclose(m.accumulated(), want, rtol=1e-5)
+    s = utils.Metric()
+    s += torch.tensor([2.0])                                   # one-element tensors (the scalar losses): no reduction at all
+    s += torch.tensor([4.0])
+    assert float(s.accumulated()) == 3.0 and s.n == 2
+    keep = utils.Metric(collapse=False)                        # per-pixel metrics keep their shape
+    keep += torch.ones(2, 3)
+    keep += torch.zeros(2, 3)
+    assert keep.accumulated().shape == (3,) and torch.allclose(keep.accumulated(), torch.full((3,), 0.5))
